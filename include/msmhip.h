@@ -1,0 +1,162 @@
+/*
+ * msmhip.h -- C ABI of libmsmhip.so, the MI355X (gfx950) engine behind the
+ * pmarlo featurize -> TICA -> k-means -> transition-matrix -> ITS path.
+ *
+ * The reference (pmarlo, pure Python) has no FFI for this path: the seam is
+ * "Python callables taking/returning numpy arrays" (SURVEY.md section 8b).  Each
+ * entry point below therefore names the reference callable whose arithmetic it
+ * replaces (file:line relative to the pmarlo tree, src/pmarlo = S/).  The
+ * ctypes binding a pmarlo maintainer would add is shown in INTEGRATION.md and
+ * implemented in pmarlo_amd/_lib.py.
+ *
+ * Conventions
+ *   - every function returns an msm_status; 0 is success.  msm_last_error()
+ *     gives the message for the last failure on that context.
+ *   - pointers named d_* are DEVICE pointers (hipMalloc'ed, e.g. msm_malloc or
+ *     a torch tensor's data_ptr()); pointers named h_* are HOST pointers.
+ *   - matrices are row-major; `ld` is the row stride in ELEMENTS.
+ *   - all work is enqueued on the context's HIP stream; nothing synchronises
+ *     unless documented (msm_sync, msm_memcpy_d2h, functions with h_ outputs).
+ *   - no torch / C++ types cross this boundary.
+ */
+#ifndef MSMHIP_H
+#define MSMHIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct msm_ctx msm_ctx;
+typedef struct msm_event msm_event;
+typedef struct msm_graph msm_graph;
+
+typedef enum {
+    MSM_OK = 0,
+    MSM_ERR_INVALID = 1,     /* bad argument            -> ValueError   */
+    MSM_ERR_HIP = 2,         /* HIP runtime failure     -> RuntimeError */
+    MSM_ERR_NOMEM = 3,       /* allocation failure      -> MemoryError  */
+    MSM_ERR_UNSUPPORTED = 4, /* shape outside kernel limits -> NotImplementedError */
+    MSM_ERR_NOCONV = 5       /* iterative solver did not converge -> RuntimeError */
+} msm_status;
+
+/* element type of a feature matrix handed to the engine */
+typedef enum { MSM_F32 = 0, MSM_F64 = 1 } msm_dtype;
+
+/* ------------------------------------------------------------------ */
+/* context, memory, timing                                              */
+/* ------------------------------------------------------------------ */
+
+/* Create a context on HIP device `device`.  `hip_stream` may be NULL (the
+ * context then owns a new non-blocking stream) or an existing hipStream_t
+ * (e.g. torch.cuda.current_stream().cuda_stream) which is borrowed. */
+msm_status msm_ctx_create(int device, void* hip_stream, msm_ctx** out);
+void msm_ctx_destroy(msm_ctx* ctx);
+const char* msm_last_error(const msm_ctx* ctx);
+/* "gfx950" etc.; number of compute units; bytes of device memory */
+msm_status msm_device_info(msm_ctx* ctx, char* arch, size_t arch_len,
+                           int* n_cu, size_t* total_mem);
+const char* msm_version(void);
+
+msm_status msm_malloc(msm_ctx* ctx, size_t bytes, void** d_out);
+msm_status msm_free(msm_ctx* ctx, void* d_ptr);
+msm_status msm_memcpy_h2d(msm_ctx* ctx, void* d_dst, const void* h_src, size_t bytes);
+msm_status msm_memcpy_d2h(msm_ctx* ctx, void* h_dst, const void* d_src, size_t bytes); /* syncs */
+msm_status msm_memcpy_d2d(msm_ctx* ctx, void* d_dst, const void* d_src, size_t bytes);
+msm_status msm_memset(msm_ctx* ctx, void* d_dst, int value, size_t bytes);
+msm_status msm_sync(msm_ctx* ctx);
+
+/* HIP events on the context's stream (bench.py times kernels with these). */
+msm_status msm_event_create(msm_ctx* ctx, msm_event** out);
+void msm_event_destroy(msm_event* ev);
+msm_status msm_event_record(msm_ctx* ctx, msm_event* ev);
+msm_status msm_event_elapsed_ms(msm_event* start, msm_event* stop, float* h_ms); /* syncs on stop */
+
+/* Stream capture: everything enqueued between begin and end becomes one
+ * hipGraph that msm_graph_launch replays (launch-bound inner loops). */
+msm_status msm_graph_begin(msm_ctx* ctx);
+msm_status msm_graph_end(msm_ctx* ctx, msm_graph** out);
+msm_status msm_graph_launch(msm_ctx* ctx, msm_graph* g);
+void msm_graph_destroy(msm_graph* g);
+
+/* ------------------------------------------------------------------ */
+/* lag-tau transition counts                                            */
+/* ------------------------------------------------------------------ */
+
+/* Unweighted lag-tau transition counts over trajectory segments.
+ * Replaces pmarlo.analysis.discretize._weighted_counts (S/analysis/
+ * discretize.py:609-645, weights=None) and, with stride=1, the deeptime
+ * "sliding" count of EstimationMixin._count_transitions_deeptime
+ * (S/markov_state_model/_estimation.py:116-156) and
+ * debug_export._build_transition_counts (S/analysis/debug_export.py:385-409).
+ *
+ * For every segment [start, stop) with stop-start > lag and every
+ * t = start, start+stride, ... < stop-lag: if labels[t] and labels[t+lag] are
+ * both in [0, k) then counts[labels[t]][labels[t+lag]] += 1.
+ * (The reference keeps pairs with both labels >= 0; labels >= k cannot occur
+ * there because k = max label + 1.  Here they are skipped, never written.)
+ *
+ * d_labels  int32 [n]           h_seg_start/h_seg_stop  int64 [n_seg] (clipped to [0,n])
+ * d_counts  int64 [k*k]  OVERWRITTEN   d_pairs  int64 [1] OVERWRITTEN (may be NULL)
+ */
+msm_status msm_count_transitions(msm_ctx* ctx, const int32_t* d_labels, int64_t n,
+                                 const int64_t* h_seg_start, const int64_t* h_seg_stop,
+                                 int n_seg, int lag, int stride, int k,
+                                 int64_t* d_counts, int64_t* d_pairs);
+
+/* Weighted variant: counts[src][dst] += w[t] (weight of the STARTING frame,
+ * S/analysis/discretize.py:633-641).  d_counts is float64 [k*k]. The sum is
+ * accumulated with fp64 atomics, so it equals the reference up to summation
+ * order (exact whenever the weights are dyadic / integer valued). */
+msm_status msm_count_transitions_weighted(msm_ctx* ctx, const int32_t* d_labels,
+                                          const double* d_weights, int64_t n,
+                                          const int64_t* h_seg_start, const int64_t* h_seg_stop,
+                                          int n_seg, int lag, int stride, int k,
+                                          double* d_counts, int64_t* d_pairs);
+
+/* Lag scan: counts for n_lag lags in one launch (ITS scan,
+ * S/markov_state_model/_its.py:525-541 called once per lag).
+ * h_lags int32 [n_lag]; d_counts int64 [n_lag*k*k]; d_pairs int64 [n_lag]. */
+msm_status msm_count_transitions_lagscan(msm_ctx* ctx, const int32_t* d_labels, int64_t n,
+                                         const int64_t* h_seg_start, const int64_t* h_seg_stop,
+                                         int n_seg, const int32_t* h_lags, int n_lag, int k,
+                                         int64_t* d_counts, int64_t* d_pairs);
+
+/* Visits per state: np.bincount(labels[0<=l<k], minlength=k)
+ * (S/analysis/discretize.py:648-667, weights=None).  d_visits int64 [k]. */
+msm_status msm_state_counts(msm_ctx* ctx, const int32_t* d_labels, int64_t n, int k,
+                            int64_t* d_visits);
+
+/* ------------------------------------------------------------------ */
+/* k-means                                                              */
+/* ------------------------------------------------------------------ */
+
+/* Assign every frame to its nearest centre.
+ * Replaces _KMeansDiscretizer.transform (S/analysis/discretize.py:471-494:
+ * whiten with (x-mean)/std_safe, then sklearn predict) and the deeptime
+ * model.transform of cluster_microstates (S/markov_state_model/
+ * clustering.py:608-609).
+ *
+ *   z      = d_mean ? (x - mean[f]) / std[f] : x        (fp64, IEEE division)
+ *   dot_j  = fma chain over f = 0..d-1 of z[f]*c[j][f], starting from +0.0
+ *   dist_j = fma(-2.0, dot_j, |c_j|^2)      |c_j|^2 = fma chain of c[j][f]^2
+ *   label  = first j with minimal dist_j (strict <, ties -> lowest index)
+ *
+ * which is sklearn's argmin_j(|c_j|^2 - 2 x.c_j) (lloyd_iter_chunked_dense)
+ * with the summation order pinned; oracle/msm_oracle.c restates it with C fma().
+ *
+ * d_x  [n, ld] dtype   d_centers f64 [k, d]   d_mean/d_std f64 [d] or NULL
+ * d_labels int32 [n]   d_mindist f64 [n] or NULL (dist_j + |z|^2 >= 0 clipped,
+ * i.e. the squared distance to the chosen centre, for inertia)
+ */
+msm_status msm_kmeans_assign(msm_ctx* ctx, const void* d_x, msm_dtype dtype, int64_t n, int d,
+                             int64_t ld, const double* d_centers, int k,
+                             const double* d_mean, const double* d_std,
+                             int32_t* d_labels, double* d_mindist);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MSMHIP_H */

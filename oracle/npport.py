@@ -1,0 +1,410 @@
+"""numpy / scipy / scikit-learn restatement of the floating-point operators on
+pmarlo's featurize -> TICA -> k-means -> T-matrix -> ITS path.
+
+TEST INFRASTRUCTURE ONLY -- see oracle/__init__.py.  Paths cited as S/... are
+relative to the reference tree (S/ = src/pmarlo/).
+
+Pinning status (tests/test_oracle_golden.py, vectors from tests/golden/make_golden.py
+which imports the reference in the build container):
+  pinned by reference import : weighted_counts, expected_pairs, state counts,
+      normalise_counts, preprocess, estimate_top_eigenvalues, kmeans discretizer
+      (fit + transform, both sklearn branches), discretize_dataset, safe_timescales,
+      featurizer geometry (distance / angle / dihedral).
+  PARITY UNPINNED (third-party code absent from the container, restated from the
+  published algorithm of the pinned version): deeptime 0.4.5 TICA (tica_fit /
+  tica_reduce), deeptime MaximumLikelihoodMSM(reversible=False) + stationary
+  distribution + eigenvalues (ml_msm / its_from_counts), mdtraj geometry (replaced
+  by the in-repo torch extractor formula, which IS pinned).
+"""
+
+from __future__ import annotations
+
+from typing import Iterable, Sequence
+
+import numpy as np
+
+NUMERIC_MIN_POSITIVE = 1e-12       # S/constants.py:29
+NUMERIC_DIRICHLET_ALPHA = 1e-3     # S/constants.py:44
+
+
+# ---------------------------------------------------------------------------
+# counts (S/analysis/discretize.py:596-682, S/analysis/counting.py:10-68)
+# ---------------------------------------------------------------------------
+def weighted_counts(labels, n_states, lag_time, weights=None, segments=None, stride=1):
+    """_weighted_counts, S/analysis/discretize.py:609-645."""
+    labels = np.asarray(labels)
+    counts = np.zeros((n_states, n_states), dtype=np.float64)
+    if labels.size == 0 or lag_time <= 0:
+        return counts, 0
+    total = 0
+    step = max(1, int(stride))
+    segs = [(0, labels.size)] if segments is None else [
+        (max(0, int(a)), min(labels.size, int(b))) for a, b in segments]
+    for start, stop in segs:
+        if stop <= start or stop - start <= lag_time:
+            continue
+        src = labels[start:stop - lag_time:step]
+        dst = labels[start + lag_time:stop:step]
+        if src.size == 0:
+            continue
+        valid = (src >= 0) & (dst >= 0)
+        if not np.any(valid):
+            continue
+        if weights is not None:
+            np.add.at(counts, (src[valid], dst[valid]), np.asarray(weights)[start:stop - lag_time:step][valid])
+        else:
+            np.add.at(counts, (src[valid], dst[valid]), 1.0)
+        total += int(np.count_nonzero(valid))
+    return counts, total
+
+
+def expected_pairs(lengths: Iterable[int], tau: int, stride=1) -> int:
+    """S/analysis/counting.py:10-68."""
+    lengths = [int(v) for v in lengths]
+    strides = [int(v) for v in stride] if isinstance(stride, Iterable) else [int(stride)]
+    total = 0
+    for idx, length in enumerate(lengths):
+        eff = length - tau
+        if length <= 0 or eff <= 0:
+            continue
+        step = strides[idx] if idx < len(strides) else strides[-1]
+        total += 1 + (eff - 1) // step
+    return total
+
+
+def normalise_counts(C):
+    """_normalise_counts, S/analysis/discretize.py:678-682 (zero rows stay 0)."""
+    C = np.asarray(C, dtype=np.float64)
+    rs = C.sum(axis=1, keepdims=True)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        return np.divide(C, rs, out=np.zeros_like(C), where=rs > 0)
+
+
+# ---------------------------------------------------------------------------
+# preprocessing + TICA
+# ---------------------------------------------------------------------------
+def preprocess(X, scale=True):
+    """reduction._preprocess, S/markov_state_model/reduction.py:13-40.
+
+    SimpleImputer(mean) (all-NaN column -> 0) then StandardScaler(with_mean=True,
+    with_std=scale): population std (ddof=0), zero std -> 1."""
+    Xp = np.array(X, dtype=float)
+    if Xp.size == 0:
+        return np.zeros_like(Xp)
+    nan = np.isnan(Xp)
+    if nan.any():
+        cnt = (~nan).sum(axis=0)
+        col_mean = np.where(cnt > 0, np.where(nan, 0.0, Xp).sum(axis=0) / np.maximum(cnt, 1), 0.0)
+        Xp = np.where(nan, col_mean[None, :], Xp)
+    mean = Xp.mean(axis=0)
+    out = Xp - mean
+    if scale:
+        std = np.sqrt(((Xp - mean) ** 2).mean(axis=0))
+        std = np.where(std < 10 * np.finfo(float).eps, 1.0, std)
+        out = out / std
+    return np.nan_to_num(out, nan=0.0)
+
+
+def estimate_top_eigenvalues(outputs, idx_t, idx_tau, n_out):
+    """_estimate_top_eigenvalues, S/features/deeptica/core/trainer_api.py:632-656."""
+    y_t = outputs[idx_t]
+    y_tau = outputs[idx_tau]
+    y_t_c = y_t - y_t.mean(axis=0, keepdims=True)
+    y_tau_c = y_tau - y_tau.mean(axis=0, keepdims=True)
+    n = max(1, y_t_c.shape[0] - 1)
+    C0 = (y_t_c.T @ y_t_c) / float(n)
+    Ct = (y_t_c.T @ y_tau_c) / float(n)
+    evals, evecs = np.linalg.eigh((C0 + C0.T) * 0.5)
+    evals = np.clip(evals, NUMERIC_MIN_POSITIVE, None)
+    inv_sqrt = evecs @ np.diag(1.0 / np.sqrt(evals)) @ evecs.T
+    M = inv_sqrt @ Ct @ inv_sqrt.T
+    eigs = np.sort(np.linalg.eigvalsh((M + M.T) * 0.5))[::-1]
+    return eigs[: min(int(n_out), eigs.size)]
+
+
+def _sort_desc_by_norm(evals, evecs):
+    order = np.argsort(np.abs(evals))[::-1]
+    return evals[order], evecs[:, order]
+
+
+def lagged_moments(Xs: Sequence[np.ndarray], lag: int):
+    """Raw symmetric moments of deeptime's Covariance(lagtime, remove_data_mean=True,
+    reversible=True, bessels_correction=False) -- the estimator TICA.fit uses
+    (deeptime 0.4.5 decomposition/_tica.py, covariance/util/_running_moments.py).
+    x = X[:-lag], y = X[lag:] per trajectory; w = 2T;
+    mean = (sum x + sum y)/w; C00 = (xc'xc + yc'yc)/w; C0t = (xc'yc + yc'xc)/w."""
+    F = Xs[0].shape[1]
+    T = 0
+    sx = np.zeros(F)
+    sy = np.zeros(F)
+    Mxx = np.zeros((F, F))
+    Mxy = np.zeros((F, F))
+    for X in Xs:
+        X = np.asarray(X, dtype=np.float64)
+        if X.shape[0] <= lag:
+            continue
+        x, y = X[:-lag], X[lag:]
+        T += x.shape[0]
+        sx += x.sum(axis=0)
+        sy += y.sum(axis=0)
+        Mxx += x.T @ x + y.T @ y
+        Mxy += x.T @ y
+    return {"T": T, "sx": sx, "sy": sy, "Mxx": Mxx, "Mxy_half": Mxy}
+
+
+def tica_fit(Xs: Sequence[np.ndarray], lag: int, dim: int | None = None, epsilon: float = 1e-6,
+             scaling: str | None = "kinetic_map"):
+    """deeptime.decomposition.TICA(lagtime, dim).fit(list).fetch_model() restated
+    (call sites S/markov_state_model/reduction.py:103-109, _features.py:200-202).
+
+    Steps (deeptime 0.4.5): reversible covariances; spd_inv_split(C00, eps) via eigh,
+    eigenvalues sorted by descending magnitude, cut-off eps (raised to |min ev| when
+    C00 has negative eigenvalues), canonical signs (largest |component| positive);
+    eigh of L' C0t L; sort descending by magnitude; eigenvectors R = L R', canonical
+    signs; kinetic_map scaling multiplies eigenvector i by eigenvalue i.  PARITY UNPINNED."""
+    m = lagged_moments(Xs, lag)
+    T = m["T"]
+    if T == 0:
+        raise ValueError("no lagged pairs")
+    w = 2.0 * T
+    mean = (m["sx"] + m["sy"]) / w
+    C00 = m["Mxx"] / w - np.outer(mean, mean)
+    Mxy = m["Mxy_half"] + m["Mxy_half"].T
+    C0t = Mxy / w - np.outer(mean, mean)
+    C00 = 0.5 * (C00 + C00.T)
+    C0t = 0.5 * (C0t + C0t.T)
+    s, V = np.linalg.eigh(C00)
+    s, V = _sort_desc_by_norm(s, V)
+    eps = epsilon
+    if s.min() < 0:
+        eps = max(eps, -s.min() + 1e-16)
+    rank = int(s.shape[0] - np.searchsorted(np.abs(s)[::-1], eps))
+    if rank == 0:
+        raise ValueError("C00 has zero rank")
+    Vm, sm = V[:, :rank].copy(), s[:rank]
+    for j in range(rank):
+        Vm[:, j] *= np.sign(Vm[np.argmax(np.abs(Vm[:, j])), j])
+    L = Vm / np.sqrt(sm)[None, :]
+    Ct = L.T @ C0t @ L
+    lam, Rt = np.linalg.eigh(0.5 * (Ct + Ct.T))
+    lam, Rt = _sort_desc_by_norm(lam, Rt)
+    R = L @ Rt
+    for j in range(R.shape[1]):
+        R[:, j] *= np.sign(R[np.argmax(np.abs(R[:, j])), j])
+    if scaling in ("kinetic_map", "km"):
+        R = R * lam[None, :]
+    out_dim = rank if dim is None else min(int(dim), rank)
+    return {"mean": mean, "eigenvalues": lam, "coefficients": R, "dim": out_dim, "rank": rank,
+            "C00": C00, "C0t": C0t, "T": T}
+
+
+def tica_transform(model, X):
+    return (np.asarray(X, dtype=np.float64) - model["mean"]) @ model["coefficients"][:, : model["dim"]]
+
+
+def tica_reduce(X, lag=1, n_components=2, scale=True):
+    """reduction.tica_reduce, S/markov_state_model/reduction.py:77-110."""
+    Xp = preprocess(X, scale=scale)
+    model = tica_fit([Xp], lag, dim=n_components)
+    return tica_transform(model, Xp)
+
+
+# ---------------------------------------------------------------------------
+# k-means (sklearn branch of the reference, S/analysis/discretize.py:406-514)
+# ---------------------------------------------------------------------------
+def kmeans_discretizer_fit(X, n_states, random_state=None):
+    """_KMeansDiscretizer.fit: mean, std(ddof=1), sklearn (MiniBatch)KMeans on whitened X."""
+    from sklearn.cluster import KMeans, MiniBatchKMeans
+
+    X = np.asarray(X, dtype=np.float64)
+    mean = X.mean(axis=0)
+    std = X.std(axis=0, ddof=1)
+    std_safe = np.where(std > 1e-10, std, 1.0)
+    Xz = (X - mean) / std_safe
+    if X.shape[0] * X.shape[1] >= 5_000_000:
+        model = MiniBatchKMeans(n_clusters=int(n_states), random_state=random_state)
+    else:
+        model = KMeans(n_clusters=int(n_states), random_state=random_state, n_init=10)
+    model.fit(Xz)
+    return {"mean": mean, "std": std, "std_safe": std_safe,
+            "centers": np.asarray(model.cluster_centers_, dtype=np.float64), "model": model}
+
+
+def kmeans_predict(Xz, centers):
+    """argmin_j(|c_j|^2 - 2 x.c_j): sklearn predict's formula (BLAS summation order)."""
+    csq = np.einsum("ij,ij->i", centers, centers)
+    d = csq[None, :] - 2.0 * (Xz @ centers.T)
+    return np.argmin(d, axis=1).astype(np.int32)
+
+
+# ---------------------------------------------------------------------------
+# MSM estimation + ITS
+# ---------------------------------------------------------------------------
+def ensure_connected_counts(C, alpha=NUMERIC_DIRICHLET_ALPHA, epsilon=NUMERIC_MIN_POSITIVE):
+    """S/utils/msm_utils.py:129-167: active = rowsum+colsum > eps; +alpha on every active cell."""
+    C = np.asarray(C, dtype=float)
+    totals = C.sum(axis=1) + C.sum(axis=0)
+    active = np.where(totals > epsilon)[0]
+    if active.size == 0:
+        return np.empty((0, 0)), active
+    return C[np.ix_(active, active)] + float(alpha), active
+
+
+def stationary_distribution(T):
+    """Left eigenvector of T for eigenvalue 1, normalised to sum 1 (what deeptime's
+    stationary_distribution returns for an irreducible dense matrix).  PARITY UNPINNED."""
+    import scipy.linalg
+
+    w, vl = scipy.linalg.eig(T, left=True, right=False)
+    i = int(np.argmin(np.abs(w - 1.0)))
+    pi = np.real(vl[:, i])
+    return pi / pi.sum()
+
+
+def ml_msm(counts, n_states=None):
+    """_finalize_transition_and_stationary, S/markov_state_model/_estimation.py:158-188:
+    MaximumLikelihoodMSM(reversible=False) on the regularised active block = row
+    normalisation; T_full = I outside the active block, pi_full = 0 there."""
+    C = np.asarray(counts, dtype=float)
+    n = C.shape[0] if n_states is None else int(n_states)
+    Ca, active = ensure_connected_counts(C)
+    T_full = np.eye(n)
+    pi_full = np.zeros(n)
+    cm = np.zeros((n, n))
+    if Ca.size:
+        T = Ca / Ca.sum(axis=1, keepdims=True)
+        pi = stationary_distribution(T)
+        T_full[np.ix_(active, active)] = T
+        pi_full[active] = pi
+        cm[np.ix_(active, active)] = Ca
+    return {"count_matrix": cm, "transition_matrix": T_full, "stationary_distribution": pi_full,
+            "active": active}
+
+
+def safe_timescales(lag, eigvals, eps=NUMERIC_MIN_POSITIVE):
+    """S/markov_state_model/utils.py:17-57."""
+    eig = np.asarray(eigvals)
+    if eig.size == 0:
+        return np.empty_like(eig, dtype=np.float64)
+    ec = eig.astype(np.complex128)
+    mag = np.abs(ec)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        ts = -float(lag) / np.log(np.clip(mag, eps, 1 - eps))
+    invalid = ~np.isfinite(mag) | (mag <= 0) | (mag >= 1)
+    real = np.isclose(ec.imag, 0.0)
+    invalid |= real & ((ec.real <= 0.0) | (ec.real >= 1.0))
+    ts = np.asarray(ts, dtype=np.float64)
+    ts[invalid] = np.nan
+    return ts
+
+
+def its_from_transition_matrix(T, lag, n_timescales):
+    """_summarize_its_stats applied to ONE transition matrix
+    (S/markov_state_model/_its.py:543-604): top (n+1) eigenvalues by magnitude
+    (deeptime eigenvalues(T, k)), re-sorted by descending real part, drop the first,
+    real part -> abs -> clip to [1e-12, 1-1e-12], safe_timescales."""
+    T = np.asarray(T, dtype=float)
+    n_eval = int(max(0, n_timescales))
+    ev = np.linalg.eigvals(T)
+    ev = ev[np.argsort(np.abs(ev))[::-1]]
+    k_req = n_eval + 1 if n_eval > 0 else 1
+    if k_req < T.shape[0]:
+        ev = ev[:k_req]
+    ev = ev[np.argsort(-np.real(ev))]
+    eig = np.real(ev[1:1 + n_eval])
+    eig = np.clip(np.abs(eig), NUMERIC_MIN_POSITIVE, 1.0 - NUMERIC_MIN_POSITIVE)
+    ts = safe_timescales(int(max(1, lag)), eig)
+    out_e = np.full(n_eval, np.nan)
+    out_t = np.full(n_eval, np.nan)
+    out_e[: eig.size] = eig
+    out_t[: ts.size] = ts
+    return out_e, out_t
+
+
+def its_from_counts(C, lag, n_timescales, alpha=NUMERIC_DIRICHLET_ALPHA):
+    """Deterministic ITS of SURVEY.md hard part 4: T = rownorm(C_active + alpha)."""
+    Ca, _ = ensure_connected_counts(C, alpha=alpha)
+    T = Ca / Ca.sum(axis=1, keepdims=True)
+    return its_from_transition_matrix(T, lag, n_timescales)
+
+
+def reversible_its_from_counts(C, lag, n_timescales):
+    """Mathematically intended form of _deterministic_its_from_counts
+    (S/markov_state_model/_its.py:742-801): C_rev = (C+C')/2, T = rownorm(C_rev),
+    eigenvalues through the pi-symmetrised matrix.  The reference takes pi from the row
+    sums of T (identically 1 -> uniform), which de-symmetrises the similarity
+    transform; that quirk is NOT replicated."""
+    C = np.asarray(C, dtype=float)
+    Cr = 0.5 * (C + C.T)
+    row = Cr.sum(axis=1)
+    rs = np.where(row == 0, 1.0, row)
+    dinv = 1.0 / np.sqrt(rs)
+    S = Cr * dinv[:, None] * dinv[None, :]
+    ev = np.sort(np.linalg.eigvalsh(S))[::-1]
+    eig = np.clip(np.abs(ev[1:1 + n_timescales]), NUMERIC_MIN_POSITIVE, 1.0 - NUMERIC_MIN_POSITIVE)
+    return eig, safe_timescales(int(max(1, lag)), eig)
+
+
+# ---------------------------------------------------------------------------
+# featurizer geometry (fp32; S/features/deeptica/ts_feature_extractor.py:423-500,
+# no PBC) and angle post-processing
+# ---------------------------------------------------------------------------
+def distances(xyz, pairs, eps=1e-12):
+    xyz = np.asarray(xyz, dtype=np.float32)
+    p = np.asarray(pairs)
+    v = xyz[:, p[:, 1], :] - xyz[:, p[:, 0], :]
+    sq = (v * v).sum(axis=-1, dtype=np.float32)
+    return np.sqrt(np.maximum(sq, np.float32(eps)))
+
+
+def dihedrals(xyz, quads, eps=1e-12):
+    xyz = np.asarray(xyz, dtype=np.float32)
+    q = np.asarray(quads)
+    e = np.float32(eps)
+    b0 = xyz[:, q[:, 1]] - xyz[:, q[:, 0]]
+    b1 = xyz[:, q[:, 2]] - xyz[:, q[:, 1]]
+    b2 = xyz[:, q[:, 3]] - xyz[:, q[:, 2]]
+    c0 = np.cross(b0, b1)
+    c1 = np.cross(b1, b2)
+    n0 = np.sqrt(np.maximum((c0 * c0).sum(-1), e))
+    n1 = np.sqrt(np.maximum((c1 * c1).sum(-1), e))
+    nb = np.sqrt(np.maximum((b1 * b1).sum(-1), e))
+    c0 = c0 / n0[..., None]
+    c1 = c1 / n1[..., None]
+    b1u = b1 / nb[..., None]
+    x = (c0 * c1).sum(-1)
+    y = (np.cross(c0, c1) * b1u).sum(-1)
+    mask = (np.abs(x) + np.abs(y)) >= e
+    ang = np.arctan2(np.where(mask, y, 0.0), np.where(mask, x, 1.0))
+    return np.where(mask, ang, 0.0).astype(np.float32)
+
+
+def angles(xyz, triplets, eps=1e-12):
+    xyz = np.asarray(xyz, dtype=np.float32)
+    t = np.asarray(triplets)
+    e = np.float32(eps)
+    v1 = xyz[:, t[:, 0]] - xyz[:, t[:, 1]]
+    v2 = xyz[:, t[:, 2]] - xyz[:, t[:, 1]]
+    dot = (v1 * v2).sum(-1)
+    n1 = np.sqrt(np.maximum((v1 * v1).sum(-1), e))
+    n2 = np.sqrt(np.maximum((v2 * v2).sum(-1), e))
+    return np.arccos(np.clip(dot / (n1 * n2), -1.0, 1.0)).astype(np.float32)
+
+
+def wrap_to_minus_pi_pi(a):
+    """S/features/builtins.py:11-14."""
+    w = ((a + np.pi) % (2 * np.pi)) - np.pi
+    return np.where(w <= -np.pi, w + 2 * np.pi, w)
+
+
+def trig_expand_periodic(X, periodic):
+    """S/api/features.py:138-180: periodic column j -> adjacent [cos, sin]."""
+    cols, mapping = [], []
+    for j in range(X.shape[1]):
+        if bool(periodic[j]):
+            cols += [np.cos(X[:, j]), np.sin(X[:, j])]
+            mapping += [j, j]
+        else:
+            cols.append(X[:, j])
+            mapping.append(j)
+    return (np.vstack(cols).T if cols else X), np.asarray(mapping, dtype=int)

@@ -1,0 +1,111 @@
+"""ctypes binding of libmsmhip.so (include/msmhip.h).
+
+The library is loaded from ``pmarlo_amd/csrc/libmsmhip.so`` only; there is no
+CPU fallback.  If the shared object is missing, or a GPU call fails, the error
+is raised -- a silent fallback would void every parity claim.
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+from pathlib import Path
+
+__all__ = ["lib", "load", "LIB_PATH", "check", "MsmError", "DECLARED_SYMBOLS"]
+
+LIB_PATH = Path(__file__).resolve().parent / "csrc" / "libmsmhip.so"
+
+MSM_OK, MSM_ERR_INVALID, MSM_ERR_HIP, MSM_ERR_NOMEM, MSM_ERR_UNSUPPORTED, MSM_ERR_NOCONV = range(6)
+MSM_F32, MSM_F64 = 0, 1
+
+
+class MsmError(RuntimeError):
+    """A HIP-side failure reported through the C ABI."""
+
+
+_vp = C.c_void_p
+_i32 = C.c_int
+_i64 = C.c_int64
+_sz = C.c_size_t
+_f64 = C.c_double
+_pp = C.POINTER(C.c_void_p)
+
+# name -> (restype, argtypes); mirrors include/msmhip.h one to one.
+_PROTOTYPES: dict[str, tuple] = {
+    "msm_version": (C.c_char_p, []),
+    "msm_ctx_create": (_i32, [_i32, _vp, _pp]),
+    "msm_ctx_destroy": (None, [_vp]),
+    "msm_last_error": (C.c_char_p, [_vp]),
+    "msm_device_info": (_i32, [_vp, C.c_char_p, _sz, C.POINTER(_i32), C.POINTER(_sz)]),
+    "msm_malloc": (_i32, [_vp, _sz, _pp]),
+    "msm_free": (_i32, [_vp, _vp]),
+    "msm_memcpy_h2d": (_i32, [_vp, _vp, _vp, _sz]),
+    "msm_memcpy_d2h": (_i32, [_vp, _vp, _vp, _sz]),
+    "msm_memcpy_d2d": (_i32, [_vp, _vp, _vp, _sz]),
+    "msm_memset": (_i32, [_vp, _vp, _i32, _sz]),
+    "msm_sync": (_i32, [_vp]),
+    "msm_event_create": (_i32, [_vp, _pp]),
+    "msm_event_destroy": (None, [_vp]),
+    "msm_event_record": (_i32, [_vp, _vp]),
+    "msm_event_elapsed_ms": (_i32, [_vp, _vp, C.POINTER(C.c_float)]),
+    "msm_graph_begin": (_i32, [_vp]),
+    "msm_graph_end": (_i32, [_vp, _pp]),
+    "msm_graph_launch": (_i32, [_vp, _vp]),
+    "msm_graph_destroy": (None, [_vp]),
+    "msm_count_transitions": (_i32, [_vp, _vp, _i64, _vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp]),
+    "msm_count_transitions_weighted": (
+        _i32, [_vp, _vp, _vp, _i64, _vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp]),
+    "msm_count_transitions_lagscan": (_i32, [_vp, _vp, _i64, _vp, _vp, _i32, _vp, _i32, _i32, _vp, _vp]),
+    "msm_state_counts": (_i32, [_vp, _vp, _i64, _i32, _vp]),
+    "msm_kmeans_assign": (_i32, [_vp, _vp, _i32, _i64, _i32, _i64, _vp, _i32, _vp, _vp, _vp, _vp]),
+}
+
+DECLARED_SYMBOLS = tuple(_PROTOTYPES)
+
+_lib = None
+
+
+def load() -> C.CDLL:
+    """Load libmsmhip.so and attach prototypes.  Raises if it is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not LIB_PATH.exists():
+        raise ImportError(
+            f"{LIB_PATH} is missing: build it with `python -m pmarlo_amd.csrc.build` "
+            "(hipcc, gfx950).  pmarlo_amd has no CPU fallback."
+        )
+    handle = C.CDLL(str(LIB_PATH))
+    for name, (res, args) in _PROTOTYPES.items():
+        fn = getattr(handle, name)  # AttributeError if the symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    _lib = handle
+    return handle
+
+
+class _LazyLib:
+    def __getattr__(self, name):
+        return getattr(load(), name)
+
+
+lib = _LazyLib()
+
+_EXC = {
+    MSM_ERR_INVALID: ValueError,
+    MSM_ERR_HIP: MsmError,
+    MSM_ERR_NOMEM: MemoryError,
+    MSM_ERR_UNSUPPORTED: NotImplementedError,
+    MSM_ERR_NOCONV: MsmError,
+}
+
+
+def check(status: int, ctx_handle=None) -> None:
+    """Map an msm_status to the Python exception the reference would raise."""
+    if status == MSM_OK:
+        return
+    msg = ""
+    if ctx_handle:
+        raw = load().msm_last_error(ctx_handle)
+        msg = raw.decode("utf-8", "replace") if raw else ""
+    exc = _EXC.get(status, MsmError)
+    raise exc(msg or f"libmsmhip call failed with status {status}")

@@ -1,0 +1,254 @@
+// Lag-tau transition counts: LDS-binned atomics, row-block privatised.
+//
+// Layout.  labels int32 [n] in HBM (4 B/frame is the whole algorithmic read;
+// the tau-shifted read hits L2).  The k x k matrix is split into row blocks of
+// `rows` source states so that rows*k 4-byte bins fit the LDS budget; the grid
+// is (frame chunks) x (row blocks) [x lags].  A workgroup streams its chunk of
+// pair ids with coalesced loads, bins the pairs whose source state falls into
+// its row block with LDS atomics, and flushes only the non-zero bins into the
+// int64 matrix with global atomics.  Integer adds commute, so the result is
+// bit-exact and independent of scheduling.  When even 16 rows do not fit (very
+// large k) the kernel degenerates to direct global atomics.
+#include "common.h"
+
+namespace {
+
+constexpr int kThreads = 256;
+constexpr int kLdsBudgetSmall = 64 * 1024;   // 2 workgroups / CU
+constexpr int kLdsBudgetLarge = 128 * 1024;  // 1 workgroup / CU
+constexpr int kMaxRowBlocks = 16;
+
+template <bool WEIGHTED>
+struct BinT { using lds_t = unsigned int; using out_t = unsigned long long; };
+template <>
+struct BinT<true> { using lds_t = double; using out_t = double; };
+
+__device__ __forceinline__ unsigned long long wave_sum_u64(unsigned long long v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    return v;
+}
+
+// One lag.  grid = (chunks, row_blocks).
+template <bool WEIGHTED>
+__global__ __launch_bounds__(kThreads) void count_lds_kernel(
+    const int32_t* __restrict__ labels, const double* __restrict__ weights, SegTab st, int k,
+    int rows, int64_t pairs_per_chunk, typename BinT<WEIGHTED>::out_t* __restrict__ counts,
+    unsigned long long* __restrict__ pairs_out) {
+    using lds_t = typename BinT<WEIGHTED>::lds_t;
+    using out_t = typename BinT<WEIGHTED>::out_t;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    lds_t* bins = reinterpret_cast<lds_t*>(smem_raw);
+
+    const int tid = threadIdx.x;
+    const int r0 = blockIdx.y * rows;
+    const int nrows = min(rows, k - r0);
+    const int nbins = nrows * k;
+    for (int i = tid; i < nbins; i += kThreads) bins[i] = (lds_t)0;
+    __syncthreads();
+
+    const int64_t p0 = (int64_t)blockIdx.x * pairs_per_chunk;
+    const int64_t p1 = min(p0 + pairs_per_chunk, st.total_pairs);
+    const int lag = st.lag;
+    unsigned long long local_pairs = 0;
+    for (int64_t p = p0 + tid; p < p1; p += kThreads) {
+        const int64_t t = seg_pair_to_frame(st, p);
+        const int a = labels[t];
+        const int b = labels[t + lag];
+        const int ra = a - r0;
+        if ((unsigned)b < (unsigned)k && (unsigned)ra < (unsigned)nrows) {
+            if constexpr (WEIGHTED) atomicAdd(&bins[ra * k + b], weights[t]);
+            else atomicAdd(&bins[ra * k + b], 1u);
+            ++local_pairs;
+        }
+    }
+    __syncthreads();
+    out_t* dst = counts + (size_t)r0 * k;
+    for (int i = tid; i < nbins; i += kThreads) {
+        const lds_t v = bins[i];
+        if (v != (lds_t)0) atomicAdd(&dst[i], (out_t)v);
+    }
+    if (pairs_out) {
+        local_pairs = wave_sum_u64(local_pairs);
+        if ((tid & 63) == 0 && local_pairs) atomicAdd(pairs_out, local_pairs);
+    }
+}
+
+// Very large k: no privatisation, one global atomic per pair.
+template <bool WEIGHTED>
+__global__ __launch_bounds__(kThreads) void count_global_kernel(
+    const int32_t* __restrict__ labels, const double* __restrict__ weights, SegTab st, int k,
+    typename BinT<WEIGHTED>::out_t* __restrict__ counts, unsigned long long* __restrict__ pairs_out) {
+    using out_t = typename BinT<WEIGHTED>::out_t;
+    const int lag = st.lag;
+    unsigned long long local_pairs = 0;
+    const int64_t step = (int64_t)gridDim.x * kThreads;
+    for (int64_t p = (int64_t)blockIdx.x * kThreads + threadIdx.x; p < st.total_pairs; p += step) {
+        const int64_t t = seg_pair_to_frame(st, p);
+        const int a = labels[t];
+        const int b = labels[t + lag];
+        if ((unsigned)a < (unsigned)k && (unsigned)b < (unsigned)k) {
+            if constexpr (WEIGHTED) atomicAdd(&counts[(size_t)a * k + b], weights[t]);
+            else atomicAdd(&counts[(size_t)a * k + b], (out_t)1);
+            ++local_pairs;
+        }
+    }
+    if (pairs_out) {
+        local_pairs = wave_sum_u64(local_pairs);
+        if ((threadIdx.x & 63) == 0 && local_pairs) atomicAdd(pairs_out, local_pairs);
+    }
+}
+
+__global__ __launch_bounds__(kThreads) void state_counts_kernel(
+    const int32_t* __restrict__ labels, int64_t n, int k, unsigned long long* __restrict__ visits) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    unsigned int* bins = reinterpret_cast<unsigned int*>(smem_raw);
+    const bool use_lds = k <= 16384;
+    if (use_lds) {
+        for (int i = threadIdx.x; i < k; i += kThreads) bins[i] = 0;
+        __syncthreads();
+    }
+    const int64_t step = (int64_t)gridDim.x * kThreads;
+    for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < n; i += step) {
+        const int a = labels[i];
+        if ((unsigned)a < (unsigned)k) {
+            if (use_lds) atomicAdd(&bins[a], 1u);
+            else atomicAdd(&visits[a], 1ull);
+        }
+    }
+    if (use_lds) {
+        __syncthreads();
+        for (int i = threadIdx.x; i < k; i += kThreads)
+            if (bins[i]) atomicAdd(&visits[i], (unsigned long long)bins[i]);
+    }
+}
+
+struct CountPlan {
+    bool global_path;
+    int rows, row_blocks, chunks;
+    size_t lds_bytes;
+    int64_t pairs_per_chunk;
+};
+
+CountPlan plan_counts(const msm_ctx* ctx, int k, int64_t total_pairs, size_t bin_bytes) {
+    CountPlan pl{};
+    const size_t row_bytes = (size_t)k * bin_bytes;
+    size_t budget = (row_bytes * k <= (size_t)kLdsBudgetSmall) ? kLdsBudgetSmall : kLdsBudgetLarge;
+    int rows = (int)(budget / row_bytes);
+    if (rows > k) rows = k;
+    if (rows < 1 || msm_ceil_div(k, rows) > kMaxRowBlocks) {
+        pl.global_path = true;
+        pl.chunks = (int)std::min<int64_t>(std::max<int64_t>(1, msm_ceil_div(total_pairs, kThreads * 8)),
+                                           (int64_t)ctx->n_cu * 8);
+        return pl;
+    }
+    pl.global_path = false;
+    pl.row_blocks = msm_ceil_div(k, rows);
+    pl.rows = msm_ceil_div(k, pl.row_blocks);  // balance the blocks
+    pl.lds_bytes = (size_t)pl.rows * row_bytes;
+    const int wg_per_cu = pl.lds_bytes <= (size_t)kLdsBudgetSmall ? 2 : 1;
+    int chunks = std::max(1, ctx->n_cu * wg_per_cu / pl.row_blocks);
+    // keep at least ~2k pairs per workgroup so the LDS flush amortises
+    const int64_t max_chunks = std::max<int64_t>(1, total_pairs / 2048);
+    if (chunks > max_chunks) chunks = (int)max_chunks;
+    pl.chunks = chunks;
+    pl.pairs_per_chunk = (total_pairs + chunks - 1) / chunks;
+    return pl;
+}
+
+template <bool WEIGHTED>
+msm_status launch_counts(msm_ctx* ctx, const int32_t* d_labels, const double* d_weights,
+                         const SegTab& st, int k, void* d_counts, int64_t* d_pairs) {
+    using out_t = typename BinT<WEIGHTED>::out_t;
+    using lds_t = typename BinT<WEIGHTED>::lds_t;
+    MSM_HIP(ctx, hipMemsetAsync(d_counts, 0, (size_t)k * k * sizeof(out_t), ctx->stream));
+    if (d_pairs) MSM_HIP(ctx, hipMemsetAsync(d_pairs, 0, sizeof(int64_t), ctx->stream));
+    if (st.total_pairs == 0) return MSM_OK;
+    CountPlan pl = plan_counts(ctx, k, st.total_pairs, sizeof(lds_t));
+    if (pl.global_path) {
+        hipLaunchKernelGGL(count_global_kernel<WEIGHTED>, dim3(pl.chunks), dim3(kThreads), 0, ctx->stream,
+                           d_labels, d_weights, st, k, (out_t*)d_counts, (unsigned long long*)d_pairs);
+    } else {
+        auto kern = count_lds_kernel<WEIGHTED>;
+        if (pl.lds_bytes > 64 * 1024)
+            MSM_HIP(ctx, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                             (int)pl.lds_bytes));
+        hipLaunchKernelGGL(kern, dim3(pl.chunks, pl.row_blocks), dim3(kThreads), pl.lds_bytes, ctx->stream,
+                           d_labels, d_weights, st, k, pl.rows, pl.pairs_per_chunk, (out_t*)d_counts,
+                           (unsigned long long*)d_pairs);
+    }
+    MSM_CHECK_LAUNCH(ctx);
+    return MSM_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+msm_status msm_count_transitions(msm_ctx* ctx, const int32_t* d_labels, int64_t n,
+                                 const int64_t* h_seg_start, const int64_t* h_seg_stop, int n_seg,
+                                 int lag, int stride, int k, int64_t* d_counts, int64_t* d_pairs) {
+    if (!ctx) return MSM_ERR_INVALID;
+    MSM_REQUIRE(ctx, n >= 0 && k >= 1, "msm_count_transitions: need n >= 0 and k >= 1 (n=%lld k=%d)",
+                (long long)n, k);
+    MSM_REQUIRE(ctx, k <= 46340, "msm_count_transitions: k=%d too large", k);
+    MSM_REQUIRE(ctx, d_counts && (d_labels || n == 0), "msm_count_transitions: NULL pointer");
+    SegTab st;
+    msm_status rs = msm_build_segtab(ctx, n, h_seg_start, h_seg_stop, n_seg, lag, stride, &st, 0);
+    if (rs != MSM_OK) return rs;
+    return launch_counts<false>(ctx, d_labels, nullptr, st, k, d_counts, d_pairs);
+}
+
+msm_status msm_count_transitions_weighted(msm_ctx* ctx, const int32_t* d_labels,
+                                          const double* d_weights, int64_t n,
+                                          const int64_t* h_seg_start, const int64_t* h_seg_stop,
+                                          int n_seg, int lag, int stride, int k, double* d_counts,
+                                          int64_t* d_pairs) {
+    if (!ctx) return MSM_ERR_INVALID;
+    MSM_REQUIRE(ctx, n >= 0 && k >= 1, "msm_count_transitions_weighted: need n >= 0 and k >= 1");
+    MSM_REQUIRE(ctx, k <= 46340, "msm_count_transitions_weighted: k=%d too large", k);
+    MSM_REQUIRE(ctx, d_counts && ((d_labels && d_weights) || n == 0),
+                "msm_count_transitions_weighted: NULL pointer");
+    SegTab st;
+    msm_status rs = msm_build_segtab(ctx, n, h_seg_start, h_seg_stop, n_seg, lag, stride, &st, 0);
+    if (rs != MSM_OK) return rs;
+    return launch_counts<true>(ctx, d_labels, d_weights, st, k, d_counts, d_pairs);
+}
+
+msm_status msm_count_transitions_lagscan(msm_ctx* ctx, const int32_t* d_labels, int64_t n,
+                                         const int64_t* h_seg_start, const int64_t* h_seg_stop,
+                                         int n_seg, const int32_t* h_lags, int n_lag, int k,
+                                         int64_t* d_counts, int64_t* d_pairs) {
+    if (!ctx) return MSM_ERR_INVALID;
+    MSM_REQUIRE(ctx, n_lag >= 0 && (h_lags || n_lag == 0), "msm_count_transitions_lagscan: bad lag list");
+    MSM_REQUIRE(ctx, n >= 0 && k >= 1 && k <= 46340, "msm_count_transitions_lagscan: bad n/k");
+    MSM_REQUIRE(ctx, d_counts && (d_labels || n == 0), "msm_count_transitions_lagscan: NULL pointer");
+    // One launch per lag into its own k*k slice: the labels stay L2-resident
+    // across lags, and under msm_graph_begin/end the launches fuse into one graph.
+    for (int l = 0; l < n_lag; ++l) {
+        SegTab st;
+        msm_status rs = msm_build_segtab(ctx, n, h_seg_start, h_seg_stop, n_seg, h_lags[l], 1, &st, l);
+        if (rs != MSM_OK) return rs;
+        rs = launch_counts<false>(ctx, d_labels, nullptr, st, k, d_counts + (size_t)l * k * k,
+                                  d_pairs ? d_pairs + l : nullptr);
+        if (rs != MSM_OK) return rs;
+    }
+    return MSM_OK;
+}
+
+msm_status msm_state_counts(msm_ctx* ctx, const int32_t* d_labels, int64_t n, int k, int64_t* d_visits) {
+    if (!ctx) return MSM_ERR_INVALID;
+    MSM_REQUIRE(ctx, n >= 0 && k >= 1, "msm_state_counts: need n >= 0 and k >= 1");
+    MSM_REQUIRE(ctx, d_visits && (d_labels || n == 0), "msm_state_counts: NULL pointer");
+    MSM_HIP(ctx, hipMemsetAsync(d_visits, 0, (size_t)k * sizeof(int64_t), ctx->stream));
+    if (n == 0) return MSM_OK;
+    const int blocks = (int)std::min<int64_t>(std::max<int64_t>(1, msm_ceil_div(n, kThreads * 16)),
+                                              (int64_t)ctx->n_cu * 4);
+    const size_t lds = k <= 16384 ? (size_t)k * sizeof(unsigned int) : 0;
+    hipLaunchKernelGGL(state_counts_kernel, dim3(blocks), dim3(kThreads), lds, ctx->stream, d_labels, n, k,
+                       (unsigned long long*)d_visits);
+    MSM_CHECK_LAUNCH(ctx);
+    return MSM_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,286 @@
+"""Device context and buffers: the thin host-side layer over the C ABI.
+
+``Engine`` owns one ``msm_ctx`` (one HIP device, one stream).  ``DeviceArray``
+is a typed view of hipMalloc'ed memory; arrays can also wrap foreign device
+pointers (e.g. ``torch.Tensor.data_ptr()``) so collectives can run on them.
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+from typing import Iterable, Sequence
+
+import numpy as np
+
+from . import _lib
+from ._lib import check, lib
+
+__all__ = ["Engine", "DeviceArray", "get_engine", "segments_to_bounds"]
+
+
+def _dtype_code(dtype: np.dtype) -> int:
+    dtype = np.dtype(dtype)
+    if dtype == np.float32:
+        return _lib.MSM_F32
+    if dtype == np.float64:
+        return _lib.MSM_F64
+    raise TypeError(f"feature matrices must be float32 or float64, got {dtype}")
+
+
+def segments_to_bounds(
+    segments: Iterable[tuple[int, int]] | None, n: int
+) -> tuple[np.ndarray, np.ndarray]:
+    """[(start, stop), ...] -> (starts, stops) int64, clipped like
+    pmarlo.analysis.discretize._iter_segments (S/analysis/discretize.py:596-606)."""
+    if segments is None:
+        return np.zeros(1, np.int64), np.full(1, int(n), np.int64)
+    starts, stops = [], []
+    for start, stop in segments:
+        a, b = max(0, int(start)), min(int(n), int(stop))
+        if b > a:
+            starts.append(a)
+            stops.append(b)
+    return np.asarray(starts, np.int64), np.asarray(stops, np.int64)
+
+
+class DeviceArray:
+    """A shaped, typed block of device memory."""
+
+    __slots__ = ("engine", "ptr", "shape", "dtype", "_owned")
+
+    def __init__(self, engine: "Engine", ptr: int, shape, dtype, owned: bool):
+        self.engine = engine
+        self.ptr = int(ptr)
+        self.shape = tuple(int(s) for s in (shape if isinstance(shape, (tuple, list)) else (shape,)))
+        self.dtype = np.dtype(dtype)
+        self._owned = owned
+
+    @property
+    def size(self) -> int:
+        return int(np.prod(self.shape)) if self.shape else 1
+
+    @property
+    def nbytes(self) -> int:
+        return self.size * self.dtype.itemsize
+
+    def to_host(self) -> np.ndarray:
+        out = np.empty(self.shape, self.dtype)
+        if out.nbytes:
+            check(lib.msm_memcpy_d2h(self.engine.handle, out.ctypes.data, self.ptr, out.nbytes),
+                  self.engine.handle)
+        return out
+
+    def copy_from_host(self, arr: np.ndarray) -> "DeviceArray":
+        arr = np.ascontiguousarray(arr, dtype=self.dtype)
+        if arr.size != self.size:
+            raise ValueError(f"size mismatch: device {self.shape} vs host {arr.shape}")
+        if arr.nbytes:
+            check(lib.msm_memcpy_h2d(self.engine.handle, self.ptr, arr.ctypes.data, arr.nbytes),
+                  self.engine.handle)
+        return self
+
+    def zero_(self) -> "DeviceArray":
+        check(lib.msm_memset(self.engine.handle, self.ptr, 0, self.nbytes), self.engine.handle)
+        return self
+
+    def view(self, shape, dtype=None, offset_elems: int = 0) -> "DeviceArray":
+        dtype = self.dtype if dtype is None else np.dtype(dtype)
+        return DeviceArray(self.engine, self.ptr + offset_elems * self.dtype.itemsize, shape, dtype, False)
+
+    def free(self) -> None:
+        if self._owned and self.ptr and self.engine.handle:
+            lib.msm_free(self.engine.handle, self.ptr)
+        self.ptr = 0
+        self._owned = False
+
+    def __del__(self):  # pragma: no cover - best effort
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class _Event:
+    def __init__(self, engine: "Engine"):
+        self.engine = engine
+        h = C.c_void_p()
+        check(lib.msm_event_create(engine.handle, C.byref(h)), engine.handle)
+        self.handle = h
+
+    def record(self) -> "_Event":
+        check(lib.msm_event_record(self.engine.handle, self.handle), self.engine.handle)
+        return self
+
+    def elapsed_ms(self, stop: "_Event") -> float:
+        ms = C.c_float()
+        check(lib.msm_event_elapsed_ms(self.handle, stop.handle, C.byref(ms)), self.engine.handle)
+        return float(ms.value)
+
+    def __del__(self):  # pragma: no cover
+        try:
+            if self.handle:
+                lib.msm_event_destroy(self.handle)
+        except Exception:
+            pass
+
+
+class Engine:
+    """One HIP device + stream, and the kernels of the MSM path on it."""
+
+    def __init__(self, device: int = 0, stream: int | None = None):
+        h = C.c_void_p()
+        status = lib.msm_ctx_create(int(device), C.c_void_p(stream) if stream else None, C.byref(h))
+        if status != _lib.MSM_OK:
+            raise _lib.MsmError(
+                f"msm_ctx_create(device={device}) failed with status {status}: "
+                "no usable HIP device (pmarlo_amd has no CPU fallback)"
+            )
+        self.handle = h
+        self.device = int(device)
+
+    # -- plumbing -----------------------------------------------------------
+    def close(self) -> None:
+        if self.handle:
+            lib.msm_ctx_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):  # pragma: no cover
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def info(self) -> dict:
+        arch = C.create_string_buffer(64)
+        ncu = C.c_int()
+        mem = C.c_size_t()
+        check(lib.msm_device_info(self.handle, arch, 64, C.byref(ncu), C.byref(mem)), self.handle)
+        return {"arch": arch.value.decode(), "n_cu": int(ncu.value), "total_mem": int(mem.value)}
+
+    def empty(self, shape, dtype) -> DeviceArray:
+        dtype = np.dtype(dtype)
+        shape = tuple(shape) if isinstance(shape, (tuple, list)) else (int(shape),)
+        nbytes = int(np.prod(shape)) * dtype.itemsize if shape else dtype.itemsize
+        p = C.c_void_p()
+        check(lib.msm_malloc(self.handle, max(nbytes, 1), C.byref(p)), self.handle)
+        return DeviceArray(self, p.value, shape, dtype, True)
+
+    def zeros(self, shape, dtype) -> DeviceArray:
+        return self.empty(shape, dtype).zero_()
+
+    def to_device(self, arr: np.ndarray, dtype=None) -> DeviceArray:
+        arr = np.ascontiguousarray(arr, dtype=dtype)
+        return self.empty(arr.shape, arr.dtype).copy_from_host(arr)
+
+    def wrap(self, ptr: int, shape, dtype) -> DeviceArray:
+        """View foreign device memory (torch tensor data_ptr, etc.)."""
+        return DeviceArray(self, ptr, shape, dtype, False)
+
+    def sync(self) -> None:
+        check(lib.msm_sync(self.handle), self.handle)
+
+    def event(self) -> _Event:
+        return _Event(self)
+
+    def graph_begin(self) -> None:
+        check(lib.msm_graph_begin(self.handle), self.handle)
+
+    def graph_end(self):
+        g = C.c_void_p()
+        check(lib.msm_graph_end(self.handle, C.byref(g)), self.handle)
+        return g
+
+    def graph_launch(self, g) -> None:
+        check(lib.msm_graph_launch(self.handle, g), self.handle)
+
+    def graph_destroy(self, g) -> None:
+        lib.msm_graph_destroy(g)
+
+    # -- transition counts ----------------------------------------------------
+    @staticmethod
+    def _seg_ptrs(starts: np.ndarray, stops: np.ndarray):
+        starts = np.ascontiguousarray(starts, np.int64)
+        stops = np.ascontiguousarray(stops, np.int64)
+        if starts.shape != stops.shape:
+            raise ValueError("segment starts/stops differ in length")
+        return starts, stops
+
+    def count_transitions(self, labels: DeviceArray, k: int, lag: int, *, starts=None, stops=None,
+                          stride: int = 1, out: DeviceArray | None = None,
+                          pairs: DeviceArray | None = None) -> tuple[DeviceArray, DeviceArray]:
+        n = labels.size
+        if starts is None:
+            starts, stops = segments_to_bounds(None, n)
+        starts, stops = self._seg_ptrs(starts, stops)
+        out = out if out is not None else self.empty((k, k), np.int64)
+        pairs = pairs if pairs is not None else self.empty((1,), np.int64)
+        check(lib.msm_count_transitions(self.handle, labels.ptr, n, starts.ctypes.data, stops.ctypes.data,
+                                        len(starts), int(lag), int(stride), int(k), out.ptr, pairs.ptr),
+              self.handle)
+        return out, pairs
+
+    def count_transitions_weighted(self, labels: DeviceArray, weights: DeviceArray, k: int, lag: int, *,
+                                   starts=None, stops=None, stride: int = 1,
+                                   out: DeviceArray | None = None, pairs: DeviceArray | None = None):
+        n = labels.size
+        if weights.size != n or weights.dtype != np.float64:
+            raise ValueError("weights must be float64 with one entry per label")
+        if starts is None:
+            starts, stops = segments_to_bounds(None, n)
+        starts, stops = self._seg_ptrs(starts, stops)
+        out = out if out is not None else self.empty((k, k), np.float64)
+        pairs = pairs if pairs is not None else self.empty((1,), np.int64)
+        check(lib.msm_count_transitions_weighted(self.handle, labels.ptr, weights.ptr, n, starts.ctypes.data,
+                                                 stops.ctypes.data, len(starts), int(lag), int(stride),
+                                                 int(k), out.ptr, pairs.ptr), self.handle)
+        return out, pairs
+
+    def count_transitions_lagscan(self, labels: DeviceArray, k: int, lags: Sequence[int], *, starts=None,
+                                  stops=None, out: DeviceArray | None = None,
+                                  pairs: DeviceArray | None = None):
+        n = labels.size
+        lags_arr = np.ascontiguousarray(lags, np.int32)
+        if starts is None:
+            starts, stops = segments_to_bounds(None, n)
+        starts, stops = self._seg_ptrs(starts, stops)
+        L = len(lags_arr)
+        out = out if out is not None else self.empty((L, k, k), np.int64)
+        pairs = pairs if pairs is not None else self.empty((L,), np.int64)
+        check(lib.msm_count_transitions_lagscan(self.handle, labels.ptr, n, starts.ctypes.data,
+                                                stops.ctypes.data, len(starts), lags_arr.ctypes.data, L,
+                                                int(k), out.ptr, pairs.ptr), self.handle)
+        return out, pairs
+
+    def state_counts(self, labels: DeviceArray, k: int, out: DeviceArray | None = None) -> DeviceArray:
+        out = out if out is not None else self.empty((k,), np.int64)
+        check(lib.msm_state_counts(self.handle, labels.ptr, labels.size, int(k), out.ptr), self.handle)
+        return out
+
+    # -- k-means --------------------------------------------------------------
+    def kmeans_assign(self, x: DeviceArray, centers: DeviceArray, *, mean: DeviceArray | None = None,
+                      std: DeviceArray | None = None, labels: DeviceArray | None = None,
+                      mindist: DeviceArray | None = None) -> DeviceArray:
+        n, d = x.shape
+        k, dc = centers.shape
+        if dc != d:
+            raise ValueError(f"centres have {dc} features, data has {d}")
+        if centers.dtype != np.float64:
+            raise TypeError("centres must be float64")
+        labels = labels if labels is not None else self.empty((n,), np.int32)
+        check(lib.msm_kmeans_assign(self.handle, x.ptr, _dtype_code(x.dtype), n, d, d, centers.ptr, k,
+                                    mean.ptr if mean is not None else None,
+                                    std.ptr if std is not None else None, labels.ptr,
+                                    mindist.ptr if mindist is not None else None), self.handle)
+        return labels
+
+
+_ENGINES: dict[int, Engine] = {}
+
+
+def get_engine(device: int = 0) -> Engine:
+    """Process-wide engine per device (operator shims share it)."""
+    eng = _ENGINES.get(device)
+    if eng is None or not eng.handle:
+        eng = Engine(device)
+        _ENGINES[device] = eng
+    return eng

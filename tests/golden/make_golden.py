@@ -1,0 +1,266 @@
+"""Generate the golden vectors under tests/golden/ by IMPORTING THE REFERENCE.
+
+Run in the build container only (the reference tree does not travel):
+
+    PYTHONPATH=/root/reference/src python tests/golden/make_golden.py
+
+Every array written here is either an input (seeded synthetic data, or
+coordinates parsed from the reference's data/*.pdb) or the output of a reference
+function on that input.  No reference source text is stored.  The functions
+exercised are the importable half of the path:
+pmarlo.analysis.{discretize,counting,debug_export,msm}, reduction._preprocess,
+trainer_api._estimate_top_eigenvalues, utils.safe_timescales and the torch
+feature extractor.
+"""
+
+from __future__ import annotations
+
+import hashlib
+import json
+import sys
+from pathlib import Path
+from types import SimpleNamespace
+
+import numpy as np
+
+REF = Path("/root/reference")
+OUT = Path(__file__).resolve().parent
+sys.path.insert(0, str(REF / "src"))
+
+from pmarlo.analysis import discretize as ref_disc  # noqa: E402
+from pmarlo.analysis.counting import expected_pairs as ref_expected_pairs  # noqa: E402
+from pmarlo.analysis.debug_export import compute_analysis_debug  # noqa: E402
+from pmarlo.analysis.msm import prepare_msm_discretization  # noqa: E402
+from pmarlo.features.deeptica.core.trainer_api import _estimate_top_eigenvalues  # noqa: E402
+from pmarlo.features.deeptica.ts_feature_extractor import (  # noqa: E402
+    build_feature_extractor_module,
+    canonicalize_feature_spec,
+)
+from pmarlo.markov_state_model.reduction import _preprocess  # noqa: E402
+from pmarlo.markov_state_model.utils import safe_timescales  # noqa: E402
+
+
+def sha(a: np.ndarray) -> str:
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+# ---- generators (same recipes as the reference's perf/integration tests) ----
+def correlated_series(n_frames, n_features, seed):
+    """tests/perf/test_tica_perf.py:65-81 recipe (AR(1) latents), loop form."""
+    rng = np.random.default_rng(seed)
+    latent = np.zeros((n_frames, 3))
+    for t in range(1, n_frames):
+        latent[t, 0] = 0.985 * latent[t - 1, 0] + rng.normal(scale=0.05)
+        latent[t, 1] = 0.950 * latent[t - 1, 1] + rng.normal(scale=0.08)
+        latent[t, 2] = rng.normal(scale=0.5)
+    mixing = rng.normal(scale=0.7, size=(3, n_features))
+    noise = rng.normal(scale=0.05, size=(n_frames, n_features))
+    return (latent @ mixing + noise).astype(np.float32)
+
+
+def gaussian_clusters(n_clusters, per, d, seed):
+    """tests/perf/test_discretize_assignment_perf.py:30-48 recipe."""
+    rng = np.random.default_rng(seed)
+    centers = rng.normal(loc=0.0, scale=5.0, size=(n_clusters, d))
+    data = np.vstack([c + rng.normal(scale=0.2, size=(per, d)) for c in centers])
+    return data.astype(np.float64), centers
+
+
+def two_well_labels(n, tau_corr, seed):
+    """tests/integration/test_msm_synthetic.py:11-26 recipe."""
+    rng = np.random.default_rng(seed)
+    x = np.zeros(n)
+    for t in range(1, n):
+        f = -4.0 * x[t - 1] * (x[t - 1] ** 2 - 1.0)
+        x[t] = x[t - 1] + f / tau_corr + np.sqrt(2.0 / tau_corr) * rng.normal()
+    return (x > 0).astype(np.int32)
+
+
+def read_pdb_models(path):
+    models, cur, names = [], [], []
+    first = True
+    for line in open(path):
+        rec = line[:6]
+        if rec in ("ATOM  ", "HETATM"):
+            cur.append([float(line[30:38]), float(line[38:46]), float(line[46:54])])
+            if first:
+                names.append(line[12:16].strip())
+        elif rec == "ENDMDL":
+            models.append(cur)
+            cur = []
+            first = False
+    if cur:
+        models.append(cur)
+    return np.asarray(models, dtype=np.float64) / 10.0, names  # nm
+
+
+# ---- 1. counts ---------------------------------------------------------------
+def golden_counts():
+    rng = np.random.default_rng(7)
+    out = {}
+    lab = rng.integers(0, 7, size=5000).astype(np.int32)
+    lab[rng.random(5000) < 0.03] = -1
+    w = rng.random(5000)
+    segs = [(0, 1200), (1200, 1210), (1210, 3700), (3700, 5000)]
+    cases = [
+        ("plain", dict(lag_time=3), None),
+        ("segs", dict(lag_time=5, segments=segs), None),
+        ("stride", dict(lag_time=4, segments=segs, stride=3), None),
+        ("weighted", dict(lag_time=2, segments=segs), w),
+        ("lag_ge_len", dict(lag_time=1300, segments=segs), None),
+    ]
+    out["labels"] = lab
+    out["weights"] = w
+    out["segments"] = np.asarray(segs, dtype=np.int64)
+    for name, kw, ww in cases:
+        c, p = ref_disc._weighted_counts(lab, n_states=7, weights=ww, **kw)
+        out[f"{name}_counts"] = c
+        out[f"{name}_pairs"] = np.int64(p)
+    out["state_counts"] = ref_disc._compute_state_counts(lab, n_states=7)
+    out["normalised_plain"] = ref_disc._normalise_counts(out["plain_counts"])
+    # expected_pairs table
+    ep_in = [([10, 5, 0, 7], 3, 1), ([100], 10, [4]), ([5, 5], 5, 1), ([12, 9, 30], 2, [1, 2, 5])]
+    out["expected_pairs"] = np.asarray([ref_expected_pairs(a, b, c) for a, b, c in ep_in], dtype=np.int64)
+    # double well of tests/integration/test_msm_synthetic.py:59-68
+    z = two_well_labels(20000, 800, 11)
+    dbg = compute_analysis_debug({"dtrajs": [z.astype(int)]}, lag=400, count_mode="sliding")
+    out["two_well_labels"] = z.astype(np.uint8)
+    out["two_well_counts"] = np.asarray(dbg.counts)
+    out["two_well_total_pairs"] = np.int64(dbg.summary["total_pairs"])
+    np.savez_compressed(OUT / "counts.npz", **out)
+
+
+# ---- 2. preprocess + 3. eigenvalues ------------------------------------------
+def golden_preprocess_tica():
+    rng = np.random.default_rng(5)
+    X = (rng.normal(size=(1000, 8)) * rng.uniform(0.5, 3.0, size=8) + rng.normal(size=8)).astype(np.float32)
+    X[rng.random(X.shape) < 0.01] = np.nan
+    X[:, 6] = 2.5  # constant column: std 0 -> scale 1
+    out = {"pre_X": X, "pre_out_scale": _preprocess(X, scale=True), "pre_out_noscale": _preprocess(X, scale=False)}
+    Y = correlated_series(4000, 8, 21)
+    lag = 10
+    idx_t = np.arange(0, Y.shape[0] - lag)
+    idx_tau = idx_t + lag
+    Yp = _preprocess(Y, scale=True)
+    ev = _estimate_top_eigenvalues(Yp, idx_t, idx_tau, SimpleNamespace(n_out=8))
+    out.update(tica_X=Y, tica_lag=np.int64(lag), tica_top_eigs=np.asarray(ev))
+    np.savez_compressed(OUT / "tica.npz", **out)
+
+
+# ---- 4. k-means discretizer ---------------------------------------------------
+def golden_kmeans():
+    out = {}
+    X, _ = gaussian_clusters(6, 200, 4, 21)
+    disc = ref_disc._KMeansDiscretizer(6, random_state=0)
+    disc.fit(X)
+    out.update(km_X=X, km_mean=disc.scaler_mean_, km_std=disc.scaler_std_, km_centers=disc.centers,
+               km_labels=disc.transform(X))
+    Xq, _ = gaussian_clusters(6, 50, 4, 52)
+    out.update(km_Xq=Xq, km_labels_q=disc.transform(Xq))
+    # AR(1) data, more centres than blobs (near-tie rich)
+    Y = correlated_series(3000, 4, 3).astype(np.float64)
+    d2 = ref_disc._KMeansDiscretizer(40, random_state=1)
+    d2.fit(Y)
+    out.update(ar_X=Y, ar_mean=d2.scaler_mean_, ar_std=d2.scaler_std_, ar_centers=d2.centers,
+               ar_labels=d2.transform(Y))
+    # MiniBatch branch (n*f >= 5e6): input regenerated from the seed in the test
+    Xb, _ = gaussian_clusters(50, 10000, 10, 99)
+    d3 = ref_disc._KMeansDiscretizer(50, random_state=0)
+    d3.fit(Xb)
+    lb = d3.transform(Xb)
+    out.update(mb_input_sha=np.frombuffer(bytes.fromhex(sha(Xb)), dtype=np.uint8),
+               mb_mean=d3.scaler_mean_, mb_std=d3.scaler_std_, mb_centers=d3.centers,
+               mb_labels_head=lb[:8192], mb_labels_sha=np.frombuffer(bytes.fromhex(sha(lb)), dtype=np.uint8),
+               mb_bincount=np.bincount(lb, minlength=50).astype(np.int64),
+               mb_is_minibatch=np.bool_(type(d3.model).__name__ == "MiniBatchKMeans"))
+    np.savez_compressed(OUT / "kmeans.npz", **out)
+
+
+# ---- 6. discretize_dataset ----------------------------------------------------
+def golden_discretize():
+    rng = np.random.default_rng(17)
+    train, _ = gaussian_clusters(5, 120, 3, 31)
+    perm = rng.permutation(train.shape[0])
+    # make it a time series with metastability: sort blocks then jitter order locally
+    train = train[np.argsort(perm // 40, kind="stable")]
+    val, _ = gaussian_clusters(5, 20, 3, 31)
+    test, _ = gaussian_clusters(5, 10, 3, 31)
+    w = rng.uniform(0.5, 1.5, size=train.shape[0])
+    ds = {"splits": {
+        "train": {"X": train, "segments": [{"length": 250}, {"start": 250, "stop": 600, "stride": 2}]},
+        "val": {"X": val},
+        "test": {"X": test},
+    }}
+    res = prepare_msm_discretization(ds, n_microstates=8, lag_time=2, random_state=3,
+                                     frame_weights={"train": w})
+    out = dict(train=train, val=val, test=test, weights=w, centers=res.centers, counts=res.counts,
+               transition_matrix=res.transition_matrix, diag_mass=np.float64(res.diag_mass),
+               state_counts=res.state_counts, counts_before_prune=res.counts_before_prune,
+               a_train=res.assignments["train"], a_val=res.assignments["val"], a_test=res.assignments["test"])
+    meta = dict(segment_lengths=res.segment_lengths, segment_strides=res.segment_strides,
+                counted_pairs=res.counted_pairs, expected_pairs=res.expected_pairs,
+                fingerprint={k: v for k, v in res.fingerprint.items() if k != "scaler"},
+                scaler=res.fingerprint["scaler"], lag_time=res.lag_time, cluster_mode=res.cluster_mode,
+                artifacts_keys=sorted(ds["__artifacts__"].keys()))
+    np.savez_compressed(OUT / "discretize.npz", **out)
+    (OUT / "discretize.json").write_text(json.dumps(meta, indent=1, sort_keys=True))
+
+
+# ---- 7. safe_timescales --------------------------------------------------------
+def golden_timescales():
+    eig = np.array([0.2, 0.5, 0.8, 0.95, 1.0, 1.2, 0.0, -0.3, 1e-14, 1 - 1e-14, np.nan])
+    ceig = np.array([0.95 * np.exp(1j * np.pi / 4), 0.5 + 0.5j, -0.2 + 0j, 0.9 + 1e-12j, 1.1j])
+    np.savez_compressed(OUT / "timescales.npz", eig=eig, ts_lag25=safe_timescales(25, eig),
+                        ceig=ceig, cts_lag5=safe_timescales(5.0, ceig),
+                        eig2d=np.array([[0.2, 0.5], [0.8, 0.95]]),
+                        ts2d=safe_timescales(25, np.array([[0.2, 0.5], [0.8, 0.95]])))
+
+
+# ---- 1'. featurizer -------------------------------------------------------------
+def golden_featurizer():
+    import torch
+
+    out = {}
+    chig, names = read_pdb_models(REF / "data" / "chignolin.pdb")
+    ca = [i for i, nm in enumerate(names) if nm == "CA"]
+    pairs = [(ca[i], ca[j]) for i in range(len(ca)) for j in range(i + 1, len(ca))]
+    rng = np.random.default_rng(1234)
+    xyz = np.tile(chig, (2, 1, 1)).astype(np.float32)
+    xyz[18:] += rng.normal(0, 0.02, size=xyz[18:].shape).astype(np.float32)
+    spec = canonicalize_feature_spec({"use_pbc": False, "features": [
+        {"type": "distance", "atoms": list(p)} for p in pairs]})
+    ext = build_feature_extractor_module(spec).eval()
+    box = torch.eye(3)
+    d = np.stack([ext(torch.from_numpy(f), box).numpy() for f in xyz])
+    out.update(chig_xyz=xyz, chig_ca=np.asarray(ca, np.int32), chig_pairs=np.asarray(pairs, np.int32), chig_dist=d)
+
+    ala, _ = read_pdb_models(REF / "data" / "alanine-dipeptide.pdb")
+    quads = [[4, 6, 8, 14], [6, 8, 14, 16]]
+    trip = [[4, 6, 8], [6, 8, 14], [8, 14, 16]]
+    axyz = np.tile(ala, (64, 1, 1)).astype(np.float32)
+    axyz[1:] += rng.normal(0, 0.03, size=axyz[1:].shape).astype(np.float32)
+    spec2 = canonicalize_feature_spec({"use_pbc": False, "features": (
+        [{"type": "dihedral", "atoms": q} for q in quads] + [{"type": "angle", "atoms": t} for t in trip])})
+    ext2 = build_feature_extractor_module(spec2).eval()
+    f2 = np.stack([ext2(torch.from_numpy(f), box).numpy() for f in axyz])
+    out.update(ala_xyz=axyz, ala_quads=np.asarray(quads, np.int32), ala_triplets=np.asarray(trip, np.int32),
+               ala_dihedrals=f2[:, :2], ala_angles=f2[:, 2:])
+    # unit-cube known answer of tests/features/deeptica/test_ts_feature_extractor.py:44-74
+    cube = np.array([[0, 0, 0], [1, 0, 0], [1, 1, 0], [1, 1, 1]], dtype=np.float32)
+    spec3 = canonicalize_feature_spec({"use_pbc": False, "features": [
+        {"type": "distance", "atoms": [0, 1]}, {"type": "angle", "atoms": [0, 1, 2]},
+        {"type": "dihedral", "atoms": [0, 1, 2, 3]}]})
+    out.update(cube_xyz=cube[None], cube_feats=build_feature_extractor_module(spec3).eval()(
+        torch.from_numpy(cube), box).numpy())
+    np.savez_compressed(OUT / "featurizer.npz", **out)
+
+
+if __name__ == "__main__":
+    golden_counts()
+    golden_preprocess_tica()
+    golden_kmeans()
+    golden_discretize()
+    golden_timescales()
+    golden_featurizer()
+    for p in sorted(OUT.glob("*.np*")) + sorted(OUT.glob("*.json")):
+        print(f"{p.name:24s} {p.stat().st_size / 1024:8.1f} KB")
