@@ -130,6 +130,75 @@ msm_status msm_state_counts(msm_ctx* ctx, const int32_t* d_labels, int64_t n, in
                             int64_t* d_visits);
 
 /* ------------------------------------------------------------------ */
+/* standardisation moments, time-lagged covariance, TICA               */
+/* ------------------------------------------------------------------ */
+
+/* Column moments of X [n, ld].  Replaces the statistics half of
+ * reduction._preprocess (S/markov_state_model/reduction.py:13-40: SimpleImputer
+ * mean + StandardScaler, ddof = 0) and of _KMeansDiscretizer.fit
+ * (S/analysis/discretize.py:446-447: np.mean / np.std(ddof=1)).
+ * NaN entries are skipped (the reference imputes them with the column mean,
+ * which leaves mean and the centred sum of squares unchanged except for the
+ * divisor, see msm_moments_finalize).
+ *
+ * _partial writes raw sums d_sums = [cnt F][S1 F][S2 F] with S1 = sum(x-shift),
+ * S2 = sum((x-shift)^2); d_shift NULL means "row 0 of X" (NaN -> 0) and the
+ * shift used is returned in d_shift_out [F] (may be NULL).  Shards that share
+ * one shift vector all-reduce d_sums by plain summation.
+ * _finalize: mean = shift + S1/cnt, std = sqrt((S2 - S1^2/cnt)/(cnt - ddof)).
+ * msm_column_moments = partial + finalize.  d_count [F] f64 may be NULL. */
+msm_status msm_column_moments_partial(msm_ctx* ctx, const void* d_x, msm_dtype dtype, int64_t n, int F,
+                                      int64_t ld, const double* d_shift, double* d_sums,
+                                      double* d_shift_out);
+msm_status msm_moments_finalize(msm_ctx* ctx, const double* d_sums, const double* d_shift, int F,
+                                int ddof, double* d_mean, double* d_std, double* d_count);
+msm_status msm_column_moments(msm_ctx* ctx, const void* d_x, msm_dtype dtype, int64_t n, int F,
+                              int64_t ld, int ddof, double* d_mean, double* d_std, double* d_count);
+
+/* Raw time-lagged moments on the fp64 matrix cores.  Replaces the covariance
+ * accumulation inside deeptime TICA.fit as called by reduction.tica_reduce
+ * (S/markov_state_model/reduction.py:103-109) and FeaturesMixin._maybe_apply_tica
+ * (S/markov_state_model/_features.py:194-202): per segment x = X[:-lag],
+ * y = X[lag:] (pairs never cross segments), reversible estimator.
+ * With z = x - shift (NaN -> 0, i.e. imputed to the column mean):
+ *   d_moments = [M00 F*F][M0t F*F][sx F][sy F][T]   (2F^2 + 2F + 1 doubles)
+ *   M00 = sum_{X0} z z' + sum_{Yt} z z',  M0t = sum_pairs z_t z_{t+lag}',
+ *   sx / sy = column sums over X0 / Yt, T = number of pairs.
+ * Un-normalised on purpose: shards all-reduce d_moments by summation
+ * (they must share d_shift).  At most 16 segments per call; F <= 64. */
+msm_status msm_lagged_moments(msm_ctx* ctx, const void* d_x, msm_dtype dtype, int64_t n, int F, int64_t ld,
+                              const int64_t* h_seg_start, const int64_t* h_seg_stop, int n_seg, int lag,
+                              const double* d_shift, double* d_moments);
+
+/* TICA solve on the device (deeptime 0.4.5 TICA._decomposition semantics):
+ *   mean = (sx+sy)/(2T); C00 = M00/(2T) - mean mean'; C0t = (M0t+M0t')/(2T) - mean mean'
+ *   (all divided by d_scale[i]*d_scale[j] when d_scale != NULL, i.e. covariances of
+ *   the standardised data (x-shift)/scale);
+ *   C00 = V S V' (Jacobi), keep |s| >= epsilon, canonical signs, L = V S^-1/2;
+ *   eigh(L' C0t L), sort by descending magnitude, R = L R', canonical signs,
+ *   kinetic_map != 0: column i of R scaled by eigenvalue i.
+ * Outputs: d_eigvals [F] (0 beyond rank), d_coeffs [F, F] row-major with column i
+ * = i-th TICA component (0 beyond rank), d_mean [F] = symmetric mean in
+ * standardised coordinates, d_rank int32 [1].  One launch, no host sync. */
+msm_status msm_tica_solve(msm_ctx* ctx, const double* d_moments, const double* d_scale, int F,
+                          double epsilon, int kinetic_map, double* d_eigvals, double* d_coeffs,
+                          double* d_mean, int* d_rank);
+
+/* Y[t][c] = sum_f (((x[t][f] - mu[f]) * inv_sigma[f]) - mean2[f]) * W[f][c], fp64 FMA chain
+ * over ascending f.  Replaces model.transform(X_prep) of tica_reduce
+ * (S/markov_state_model/reduction.py:109).  NaN -> 0 after centring.
+ * d_mean2 may be NULL.  W is [F, ldw] (first d columns used), Y is [n, ldy] f64. */
+msm_status msm_project(msm_ctx* ctx, const void* d_x, msm_dtype dtype, int64_t n, int F, int64_t ld,
+                       const double* d_mu, const double* d_inv_sigma, const double* d_mean2,
+                       const double* d_w, int d, int64_t ldw, double* d_y, int64_t ldy);
+
+/* Symmetric eigendecomposition by parallel cyclic Jacobi (n <= 256), ascending
+ * eigenvalues d_w [n], eigenvectors in the columns of d_v [n, n] (may be NULL).
+ * Replaces np.linalg.eigh on the path (e.g. _estimate_top_eigenvalues,
+ * S/features/deeptica/core/trainer_api.py:646-651). d_sweeps int32 [1] may be NULL. */
+msm_status msm_eigh(msm_ctx* ctx, const double* d_a, int n, double* d_w, double* d_v, int* d_sweeps);
+
+/* ------------------------------------------------------------------ */
 /* k-means                                                              */
 /* ------------------------------------------------------------------ */
 

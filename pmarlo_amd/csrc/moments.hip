@@ -1,0 +1,270 @@
+// Column moments (mean / std) and the fused standardise+project kernel.
+//
+// Both are single passes over X [n, ld] (f32 or f64) and HBM-bound:
+//   moments : read F*s bytes per frame, 2F flop
+//   project : read F*s, write d*8 bytes per frame, 2*F*d flop (d << F)
+// Lanes span consecutive features of a row so every wave load is a contiguous
+// run of the row-major matrix.  Reductions are two-stage (per-workgroup slab in
+// scratch, then one fixed-order pass), so results are run-to-run reproducible.
+#include "common.h"
+
+namespace {
+
+constexpr int kThreads = 256;
+
+template <typename T>
+__device__ __forceinline__ double ld_f64(const T* p) { return (double)(*p); }
+
+// ---------------------------------------------------------------------------
+// moments: per column  cnt = #finite-or-inf (non-NaN), S1 = sum(x - shift), S2 = sum((x - shift)^2)
+// shift = caller-provided vector or row 0 of X (NaN -> 0).
+// partial layout: [block][3][F]
+// ---------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(kThreads) void moments_partial_kernel(
+    const T* __restrict__ x, int64_t n, int F, int64_t ld, const double* __restrict__ shift_in,
+    int tf, int64_t rows_per_block, double* __restrict__ partial) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    double* red = reinterpret_cast<double*>(smem_raw);  // [3][kThreads]
+    const int tid = threadIdx.x;
+    const int fx = tid % tf;
+    const int ry = tid / tf;
+    const int rp = kThreads / tf;
+    const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
+    const int64_t r1 = min(r0 + rows_per_block, n);
+    double* out = partial + (size_t)blockIdx.x * 3 * F;
+    for (int f0 = 0; f0 < F; f0 += tf) {
+        const int f = f0 + fx;
+        double cnt = 0.0, s1 = 0.0, s2 = 0.0;
+        if (f < F) {
+            double sh;
+            if (shift_in) sh = shift_in[f];
+            else { sh = ld_f64(x + f); if (sh != sh) sh = 0.0; }
+            int64_t r = r0 + ry;
+            // 4 independent loads in flight per lane
+            for (; r + 3 * rp < r1; r += 4 * rp) {
+                double v[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) v[u] = ld_f64(x + (r + (int64_t)u * rp) * ld + f);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    if (v[u] == v[u]) { const double dlt = v[u] - sh; cnt += 1.0; s1 += dlt; s2 = fma(dlt, dlt, s2); }
+                }
+            }
+            for (; r < r1; r += rp) {
+                const double v = ld_f64(x + r * ld + f);
+                if (v == v) { const double dlt = v - sh; cnt += 1.0; s1 += dlt; s2 = fma(dlt, dlt, s2); }
+            }
+        }
+        red[tid] = cnt; red[kThreads + tid] = s1; red[2 * kThreads + tid] = s2;
+        __syncthreads();
+        if (ry == 0 && f < F) {
+            for (int y = 1; y < rp; ++y) {  // fixed order
+                cnt += red[y * tf + fx]; s1 += red[kThreads + y * tf + fx]; s2 += red[2 * kThreads + y * tf + fx];
+            }
+            out[f] = cnt; out[F + f] = s1; out[2 * F + f] = s2;
+        }
+        __syncthreads();
+    }
+}
+
+// sums[3][F] = fixed-order sum over blocks; also records the shift used.
+template <typename T>
+__global__ void moments_reduce_kernel(const double* __restrict__ partial, int n_blocks, int F,
+                                      const T* __restrict__ x, const double* __restrict__ shift_in,
+                                      double* __restrict__ sums, double* __restrict__ shift_out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < 3 * F) {
+        double acc = 0.0;
+        for (int b = 0; b < n_blocks; ++b) acc += partial[(size_t)b * 3 * F + i];
+        sums[i] = acc;
+    }
+    if (i < F && shift_out) {
+        double sh;
+        if (shift_in) sh = shift_in[i];
+        else { sh = ld_f64(x + i); if (sh != sh) sh = 0.0; }
+        shift_out[i] = sh;
+    }
+}
+
+// mean = shift + S1/cnt ; var = (S2 - S1^2/cnt)/(cnt - ddof) ; std = sqrt(max(var, 0))
+__global__ void moments_finalize_kernel(const double* __restrict__ sums, const double* __restrict__ shift, int F,
+                                        int ddof, double* __restrict__ mean, double* __restrict__ stdv,
+                                        double* __restrict__ count) {
+    const int f = blockIdx.x * blockDim.x + threadIdx.x;
+    if (f >= F) return;
+    const double cnt = sums[f], s1 = sums[F + f], s2 = sums[2 * F + f];
+    double m = 0.0, sd = 0.0;
+    if (cnt > 0.0) {
+        m = shift[f] + s1 / cnt;
+        const double denom = cnt - (double)ddof;
+        if (denom > 0.0) {
+            double var = (s2 - s1 * s1 / cnt) / denom;
+            sd = var > 0.0 ? sqrt(var) : 0.0;
+        } else {
+            sd = __builtin_nan("");
+        }
+    }
+    mean[f] = m;
+    stdv[f] = sd;
+    if (count) count[f] = cnt;
+}
+
+// ---------------------------------------------------------------------------
+// project: Y[t][c] = sum_f ((x[t][f] - mu[f]) * inv_sigma[f] - m[f]) * W[f][c]
+// NaN inputs are imputed to the column mean (z = 0), as reduction._preprocess does.
+// Tile = 64 frames; the standardised tile sits in LDS as fp64 [64][FT+1]
+// (odd row stride -> conflict-free column walks), W as [FT][d].
+// ---------------------------------------------------------------------------
+constexpr int kProjFrames = 64;
+constexpr int kProjFT = 64;  // feature chunk
+
+template <typename T>
+__global__ __launch_bounds__(kThreads) void project_kernel(
+    const T* __restrict__ x, int64_t n, int F, int64_t ld, const double* __restrict__ mu,
+    const double* __restrict__ inv_sigma, const double* __restrict__ m2, const double* __restrict__ W, int d,
+    int64_t ldw, double* __restrict__ y, int64_t ldy) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    double* zs = reinterpret_cast<double*>(smem_raw);          // [64][FT+1]
+    double* ws = zs + kProjFrames * (kProjFT + 1);              // [FT][d]
+    const int tid = threadIdx.x;
+    const int r = tid & 63;
+    const int cg = tid >> 6;  // wave id: column group, wave-uniform
+    const int64_t n_tiles = (n + kProjFrames - 1) / kProjFrames;
+    constexpr int kMaxCols = 16;  // columns per thread (d <= 64)
+    for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const int64_t t0 = tile * kProjFrames;
+        const int rows = (int)min<int64_t>(kProjFrames, n - t0);
+        double acc[kMaxCols];
+#pragma unroll
+        for (int c = 0; c < kMaxCols; ++c) acc[c] = 0.0;
+        for (int f0 = 0; f0 < F; f0 += kProjFT) {
+            const int fc = min(kProjFT, F - f0);
+            __syncthreads();
+            for (int i = tid; i < rows * fc; i += kThreads) {
+                const int rr = i / fc, ff = i - rr * fc;
+                double v = ld_f64(x + (t0 + rr) * ld + f0 + ff);
+                double z = (v - mu[f0 + ff]) * inv_sigma[f0 + ff];
+                if (v != v) z = 0.0;
+                if (m2) z -= m2[f0 + ff];
+                zs[rr * (kProjFT + 1) + ff] = z;
+            }
+            for (int i = tid; i < fc * d; i += kThreads) {
+                const int ff = i / d, c = i - ff * d;
+                ws[i] = W[(size_t)(f0 + ff) * ldw + c];
+            }
+            __syncthreads();
+            if (r < rows) {
+                const double* zr = zs + r * (kProjFT + 1);
+#pragma unroll
+                for (int ci = 0; ci < kMaxCols; ++ci) {
+                    const int c = cg + 4 * ci;
+                    if (c < d) {
+                        double a = acc[ci];
+                        for (int ff = 0; ff < fc; ++ff) a = fma(zr[ff], ws[ff * d + c], a);
+                        acc[ci] = a;
+                    }
+                }
+            }
+        }
+        if (r < rows) {
+#pragma unroll
+            for (int ci = 0; ci < kMaxCols; ++ci) {
+                const int c = cg + 4 * ci;
+                if (c < d) y[(t0 + r) * ldy + c] = acc[ci];
+            }
+        }
+    }
+}
+
+int pick_tf(int F) {
+    int tf = 1;
+    while (tf < F && tf < kThreads) tf <<= 1;
+    return tf;
+}
+
+template <typename T>
+msm_status moments_partial_impl(msm_ctx* ctx, const T* x, int64_t n, int F, int64_t ld, const double* d_shift,
+                                double* d_sums, double* d_shift_out) {
+    const int tf = pick_tf(F);
+    const int rp = kThreads / tf;
+    int blocks = (int)std::min<int64_t>((int64_t)ctx->n_cu * 8, std::max<int64_t>(1, n / (rp * 16)));
+    const int64_t rows_per_block = (n + blocks - 1) / blocks;
+    blocks = (int)((n + rows_per_block - 1) / rows_per_block);
+    msm_status rs = msm_reserve_scratch(ctx, (size_t)blocks * 3 * F * sizeof(double));
+    if (rs != MSM_OK) return rs;
+    double* partial = (double*)ctx->scratch;
+    hipLaunchKernelGGL(moments_partial_kernel<T>, dim3(blocks), dim3(kThreads), 3 * kThreads * sizeof(double),
+                       ctx->stream, x, n, F, ld, d_shift, tf, rows_per_block, partial);
+    MSM_CHECK_LAUNCH(ctx);
+    hipLaunchKernelGGL(moments_reduce_kernel<T>, dim3(msm_ceil_div(3 * F, 256)), dim3(256), 0, ctx->stream, partial,
+                       blocks, F, x, d_shift, d_sums, d_shift_out);
+    MSM_CHECK_LAUNCH(ctx);
+    return MSM_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+msm_status msm_column_moments_partial(msm_ctx* ctx, const void* d_x, msm_dtype dtype, int64_t n, int F,
+                                      int64_t ld, const double* d_shift, double* d_sums, double* d_shift_out) {
+    if (!ctx) return MSM_ERR_INVALID;
+    MSM_REQUIRE(ctx, n >= 1 && F >= 1 && ld >= F, "msm_column_moments_partial: need n >= 1, F >= 1, ld >= F");
+    MSM_REQUIRE(ctx, d_x && d_sums, "msm_column_moments_partial: NULL pointer");
+    MSM_REQUIRE(ctx, dtype == MSM_F32 || dtype == MSM_F64, "msm_column_moments_partial: bad dtype");
+    if (dtype == MSM_F32)
+        return moments_partial_impl<float>(ctx, (const float*)d_x, n, F, ld, d_shift, d_sums, d_shift_out);
+    return moments_partial_impl<double>(ctx, (const double*)d_x, n, F, ld, d_shift, d_sums, d_shift_out);
+}
+
+msm_status msm_moments_finalize(msm_ctx* ctx, const double* d_sums, const double* d_shift, int F, int ddof,
+                                double* d_mean, double* d_std, double* d_count) {
+    if (!ctx) return MSM_ERR_INVALID;
+    MSM_REQUIRE(ctx, F >= 1 && ddof >= 0, "msm_moments_finalize: need F >= 1, ddof >= 0");
+    MSM_REQUIRE(ctx, d_sums && d_shift && d_mean && d_std, "msm_moments_finalize: NULL pointer");
+    hipLaunchKernelGGL(moments_finalize_kernel, dim3(msm_ceil_div(F, 256)), dim3(256), 0, ctx->stream, d_sums, d_shift,
+                       F, ddof, d_mean, d_std, d_count);
+    MSM_CHECK_LAUNCH(ctx);
+    return MSM_OK;
+}
+
+msm_status msm_column_moments(msm_ctx* ctx, const void* d_x, msm_dtype dtype, int64_t n, int F, int64_t ld, int ddof,
+                              double* d_mean, double* d_std, double* d_count) {
+    if (!ctx) return MSM_ERR_INVALID;
+    MSM_REQUIRE(ctx, F >= 1, "msm_column_moments: F must be >= 1");
+    // workspace after the per-block partials: [3F sums][F shift]
+    const size_t tail = (size_t)4 * F * sizeof(double);
+    const size_t head = (size_t)ctx->n_cu * 8 * 3 * F * sizeof(double);
+    msm_status rs = msm_reserve_scratch(ctx, head + tail);
+    if (rs != MSM_OK) return rs;
+    double* sums = (double*)((char*)ctx->scratch + head);
+    double* shift = sums + 3 * F;
+    rs = msm_column_moments_partial(ctx, d_x, dtype, n, F, ld, nullptr, sums, shift);
+    if (rs != MSM_OK) return rs;
+    return msm_moments_finalize(ctx, sums, shift, F, ddof, d_mean, d_std, d_count);
+}
+
+msm_status msm_project(msm_ctx* ctx, const void* d_x, msm_dtype dtype, int64_t n, int F, int64_t ld,
+                       const double* d_mu, const double* d_inv_sigma, const double* d_mean2, const double* d_w, int d,
+                       int64_t ldw, double* d_y, int64_t ldy) {
+    if (!ctx) return MSM_ERR_INVALID;
+    MSM_REQUIRE(ctx, n >= 0 && F >= 1 && d >= 1 && d <= 64, "msm_project: need n >= 0, F >= 1, 1 <= d <= 64");
+    MSM_REQUIRE(ctx, ld >= F && ldw >= d && ldy >= d, "msm_project: bad leading dimension");
+    MSM_REQUIRE(ctx, dtype == MSM_F32 || dtype == MSM_F64, "msm_project: bad dtype");
+    if (n == 0) return MSM_OK;
+    MSM_REQUIRE(ctx, d_x && d_mu && d_inv_sigma && d_w && d_y, "msm_project: NULL pointer");
+    const size_t lds = ((size_t)kProjFrames * (kProjFT + 1) + (size_t)kProjFT * d) * sizeof(double);
+    const int64_t n_tiles = (n + kProjFrames - 1) / kProjFrames;
+    const int grid = (int)std::min<int64_t>(n_tiles, (int64_t)ctx->n_cu * 8);
+    if (dtype == MSM_F32)
+        hipLaunchKernelGGL(project_kernel<float>, dim3(grid), dim3(kThreads), lds, ctx->stream, (const float*)d_x, n, F,
+                           ld, d_mu, d_inv_sigma, d_mean2, d_w, d, ldw, d_y, ldy);
+    else
+        hipLaunchKernelGGL(project_kernel<double>, dim3(grid), dim3(kThreads), lds, ctx->stream, (const double*)d_x, n,
+                           F, ld, d_mu, d_inv_sigma, d_mean2, d_w, d, ldw, d_y, ldy);
+    MSM_CHECK_LAUNCH(ctx);
+    return MSM_OK;
+}
+
+}  // extern "C"

@@ -256,6 +256,75 @@ class Engine:
         check(lib.msm_state_counts(self.handle, labels.ptr, labels.size, int(k), out.ptr), self.handle)
         return out
 
+    # -- moments / covariance / TICA -------------------------------------------
+    def column_moments(self, x: DeviceArray, ddof: int = 0):
+        """-> (mean, std, count) device arrays [F] f64 (NaN entries skipped)."""
+        n, F = x.shape
+        mean, std, cnt = (self.empty((F,), np.float64) for _ in range(3))
+        check(lib.msm_column_moments(self.handle, x.ptr, _dtype_code(x.dtype), n, F, F, int(ddof), mean.ptr,
+                                     std.ptr, cnt.ptr), self.handle)
+        return mean, std, cnt
+
+    def column_moments_partial(self, x: DeviceArray, shift: DeviceArray | None = None,
+                               sums: DeviceArray | None = None):
+        """Raw sums [cnt | S1 | S2] (3F f64) about `shift` (default: row 0) -> (sums, shift)."""
+        n, F = x.shape
+        sums = sums if sums is not None else self.empty((3 * F,), np.float64)
+        shift_out = self.empty((F,), np.float64)
+        check(lib.msm_column_moments_partial(self.handle, x.ptr, _dtype_code(x.dtype), n, F, F,
+                                             shift.ptr if shift is not None else None, sums.ptr,
+                                             shift_out.ptr), self.handle)
+        return sums, shift_out
+
+    def moments_finalize(self, sums: DeviceArray, shift: DeviceArray, F: int, ddof: int = 0):
+        mean, std, cnt = (self.empty((F,), np.float64) for _ in range(3))
+        check(lib.msm_moments_finalize(self.handle, sums.ptr, shift.ptr, F, int(ddof), mean.ptr, std.ptr,
+                                       cnt.ptr), self.handle)
+        return mean, std, cnt
+
+    def lagged_moments(self, x: DeviceArray, lag: int, shift: DeviceArray, *, starts=None, stops=None,
+                       out: DeviceArray | None = None) -> DeviceArray:
+        """Raw reversible lagged moments [M00 | M0t | sx | sy | T] (2F^2+2F+1 f64)."""
+        n, F = x.shape
+        if starts is None:
+            starts, stops = segments_to_bounds(None, n)
+        starts, stops = self._seg_ptrs(starts, stops)
+        out = out if out is not None else self.empty((2 * F * F + 2 * F + 1,), np.float64)
+        check(lib.msm_lagged_moments(self.handle, x.ptr, _dtype_code(x.dtype), n, F, F, starts.ctypes.data,
+                                     stops.ctypes.data, len(starts), int(lag), shift.ptr, out.ptr), self.handle)
+        return out
+
+    def tica_solve(self, moments: DeviceArray, F: int, *, scale: DeviceArray | None = None,
+                   epsilon: float = 1e-6, kinetic_map: bool = True):
+        """-> (eigvals [F], coeffs [F,F], mean [F], rank int32[1]) on the device."""
+        eig = self.empty((F,), np.float64)
+        W = self.empty((F, F), np.float64)
+        mean = self.empty((F,), np.float64)
+        rank = self.empty((1,), np.int32)
+        check(lib.msm_tica_solve(self.handle, moments.ptr, scale.ptr if scale is not None else None, F,
+                                 float(epsilon), int(bool(kinetic_map)), eig.ptr, W.ptr, mean.ptr, rank.ptr),
+              self.handle)
+        return eig, W, mean, rank
+
+    def project(self, x: DeviceArray, mu: DeviceArray, inv_sigma: DeviceArray, W: DeviceArray, d: int, *,
+                mean2: DeviceArray | None = None, out: DeviceArray | None = None) -> DeviceArray:
+        n, F = x.shape
+        ldw = W.shape[1]
+        out = out if out is not None else self.empty((n, d), np.float64)
+        check(lib.msm_project(self.handle, x.ptr, _dtype_code(x.dtype), n, F, F, mu.ptr, inv_sigma.ptr,
+                              mean2.ptr if mean2 is not None else None, W.ptr, int(d), ldw, out.ptr,
+                              out.shape[1]), self.handle)
+        return out
+
+    def eigh(self, a: DeviceArray, want_vectors: bool = True):
+        n = a.shape[0]
+        w = self.empty((n,), np.float64)
+        v = self.empty((n, n), np.float64) if want_vectors else None
+        sweeps = self.empty((1,), np.int32)
+        check(lib.msm_eigh(self.handle, a.ptr, n, w.ptr, v.ptr if v is not None else None, sweeps.ptr),
+              self.handle)
+        return w, v, sweeps
+
     # -- k-means --------------------------------------------------------------
     def kmeans_assign(self, x: DeviceArray, centers: DeviceArray, *, mean: DeviceArray | None = None,
                       std: DeviceArray | None = None, labels: DeviceArray | None = None,
