@@ -165,10 +165,12 @@ msm_status msm_column_moments(msm_ctx* ctx, const void* d_x, msm_dtype dtype, in
  *   M00 = sum_{X0} z z' + sum_{Yt} z z',  M0t = sum_pairs z_t z_{t+lag}',
  *   sx / sy = column sums over X0 / Yt, T = number of pairs.
  * Un-normalised on purpose: shards all-reduce d_moments by summation
- * (they must share d_shift).  At most 16 segments per call; F <= 64. */
+ * (they must share d_shift).  At most 16 segments per call; F <= 64.
+ * assume_finite != 0 skips the NaN test (callers know from msm_column_moments'
+ * d_count whether X holds NaNs; with NaNs present it must be 0). */
 msm_status msm_lagged_moments(msm_ctx* ctx, const void* d_x, msm_dtype dtype, int64_t n, int F, int64_t ld,
                               const int64_t* h_seg_start, const int64_t* h_seg_stop, int n_seg, int lag,
-                              const double* d_shift, double* d_moments);
+                              const double* d_shift, int assume_finite, double* d_moments);
 
 /* TICA solve on the device (deeptime 0.4.5 TICA._decomposition semantics):
  *   mean = (sx+sy)/(2T); C00 = M00/(2T) - mean mean'; C0t = (M0t+M0t')/(2T) - mean mean'

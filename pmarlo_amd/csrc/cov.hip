@@ -32,35 +32,21 @@ typedef double v4f64 __attribute__((ext_vector_type(4)));
 
 constexpr int kThreads = 256;
 constexpr int kWaves = kThreads / 64;
-constexpr int kUnroll = 2;  // k-groups (of 4 frames) per pipelined iteration
+constexpr int kUnroll = 1;  // k-groups (of 4 frames) per pipelined iteration (segments padded to kGroup)
 
 struct FrameTab {
     int n;    // segments longer than lag
     int lag;
     int64_t start[MSM_SEG_INLINE];
     int64_t stop[MSM_SEG_INLINE];
-    int64_t prefix[MSM_SEG_INLINE + 1];  // dense frame index prefix
-    int64_t total;                       // frames in those segments
-    int64_t pairs;                       // T
+    // Dense frame index prefix.  Every segment is padded to a multiple of kGroup
+    // frames so that a pipelined group never straddles two segments: the segment
+    // of a group is wave-uniform and lives in SGPRs.  Padding frames are masked.
+    int64_t prefix[MSM_SEG_INLINE + 1];
+    int64_t total;  // padded frames in those segments
+    int64_t pairs;  // T
 };
-
-struct FrameInfo {
-    int64_t t;
-    bool valid, in_x0, in_yt;
-};
-
-__device__ __forceinline__ FrameInfo locate_frame(const FrameTab& ft, int64_t q, int64_t q_end) {
-    FrameInfo fi;
-    fi.valid = q < q_end;
-    const int64_t qq = fi.valid ? q : 0;
-    int s = 0;
-#pragma unroll 1
-    while (s + 1 < ft.n && qq >= ft.prefix[s + 1]) ++s;
-    fi.t = ft.start[s] + (qq - ft.prefix[s]);
-    fi.in_x0 = fi.valid && (fi.t + ft.lag < ft.stop[s]);
-    fi.in_yt = fi.valid && (fi.t - ft.lag >= ft.start[s]);
-    return fi;
-}
+constexpr int kGroup = 4 * kUnroll;
 
 template <typename T>
 __device__ __forceinline__ double to_f64(T v) { return (double)v; }
@@ -76,150 +62,220 @@ struct CovShape {
 template <int NT>
 __host__ __device__ constexpr int sym_index(int ti, int tj) { return ti * NT - ti * (ti - 1) / 2 + (tj - ti); }
 
-template <typename T, int NT>
-__global__ __launch_bounds__(kThreads, 1) void cov_fused_kernel(const T* __restrict__ x, int F, int64_t ld, FrameTab ft,
-                                                               const double* __restrict__ mu,
-                                                               int64_t frames_per_wave, double* __restrict__ slabs) {
-    using S = CovShape<NT>;
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    double* red = reinterpret_cast<double*>(smem_raw);  // [kTiles*256] then [kWaves][2][NT][64]
+// Tile ownership.  With F > 32 the 16 + 10 (or 9 + 6) accumulator tiles do not fit the
+// 256 registers a wave may use at two waves per SIMD, and a lone wave per SIMD cannot
+// overlap its fp64 VALU operand preparation with its own in-order MFMA stream.  So the
+// tiles are split between two waves that walk the SAME frames (waves w and w+4 of a
+// 512-thread workgroup share a SIMD): while one wave's MFMAs occupy the matrix core the
+// other converts/centres its next operands.  Both halves load the operands (L1 hits).
+template <int NT>
+struct TileSplit {
+    static constexpr int kSym = NT * (NT + 1) / 2;
+    static constexpr int kTotal = NT * NT + kSym;
+    static constexpr int kRows0 = (NT + 1) / 2;                   // M0t tile rows of half 0
+    static constexpr int kSym0 = (kTotal + 1) / 2 - kRows0 * NT;  // first kSym0 M00 tiles -> half 0
+    // HALF < 0: the wave owns everything
+    template <int HALF> static constexpr bool own_0t(int a) { return HALF < 0 || (HALF == 0) == (a < kRows0); }
+    template <int HALF> static constexpr bool own_00(int sidx) { return HALF < 0 || (HALF == 0) == (sidx < kSym0); }
+};
 
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = tid >> 6;
+// Feature <-> (tile, row) map.  The contraction does not care which 16 features form a
+// "tile", so tile a holds features {NT*i + a : i = 0..15}: lane i then needs features
+// NT*i .. NT*i + NT-1 of its frame, ONE contiguous load of NT elements (16 bytes for
+// fp32 at F = 64), and 16 lanes cover a whole 64-feature row.
+template <typename T, int NT, bool VEC, int HALF, bool FINITE>
+__device__ __forceinline__ void cov_wave_body(const T* __restrict__ x, int F, int64_t ld, const FrameTab& ft,
+                                              const double* __restrict__ mu, int64_t frames_per_wave,
+                                              int frame_wave, int n_frame_waves, double* red, int red_wave) {
+    using S = CovShape<NT>;
+    using TS = TileSplit<NT>;
+    const int lane = threadIdx.x & 63;
     const int fi_ = lane & 15;
     const int kk = lane >> 4;
     const int lag = ft.lag;
 
     v4f64 acc0t[NT][NT];
     v4f64 acc00[S::kSym];
-    double sx[NT], sy[NT], shift[NT];
+    double ssum[NT], shift[NT];  // HALF 0 sums X0 (sx), HALF 1 sums Yt (sy); HALF < 0 keeps both
+    double ssum2[NT];
     bool fok[NT];
 #pragma unroll
     for (int a = 0; a < NT; ++a) {
 #pragma unroll
         for (int b = 0; b < NT; ++b) acc0t[a][b] = (v4f64){0.0, 0.0, 0.0, 0.0};
-        sx[a] = sy[a] = 0.0;
-        const int f = 16 * a + fi_;
+        ssum[a] = ssum2[a] = 0.0;
+        const int f = NT * fi_ + a;
         fok[a] = f < F;
         shift[a] = fok[a] ? mu[f] : 0.0;
     }
 #pragma unroll
     for (int a = 0; a < S::kSym; ++a) acc00[a] = (v4f64){0.0, 0.0, 0.0, 0.0};
 
-    const int64_t gw = (int64_t)blockIdx.x * kWaves + wave;
-    const int64_t q_begin = gw * frames_per_wave;
+    const int64_t gw = (int64_t)blockIdx.x * n_frame_waves + frame_wave;
+    const int64_t q_begin = gw * frames_per_wave;  // multiple of kGroup, wave-uniform
     const int64_t q_end = min(q_begin + frames_per_wave, ft.total);
 
-    // raw values of the group being prefetched
-    T rx[kUnroll][NT], ry[kUnroll][NT];
-    FrameInfo info[kUnroll];
-
-    auto issue_loads = [&](int64_t q0) {
+    using VT = T __attribute__((ext_vector_type(NT)));
+    // Validity never masks the A operand: an out-of-segment lane re-reads the segment's
+    // last frame (finite data) and its B operands carry weight 0, so it adds exact zeros.
+    auto load_group = [&](int64_t t, int64_t s_start, int64_t s_stop, T (&rx)[NT], T (&ry)[NT], double& wx,
+                          double& wy) {
+        wx = (t + lag < s_stop) ? 1.0 : 0.0;
+        wy = (t < s_stop && t - lag >= s_start) ? 1.0 : 0.0;
+        const int64_t tx = min(t, s_stop - 1);
+        const int64_t ty = min(t + lag, s_stop - 1);
+        const T* px = x + tx * ld + NT * fi_;
+        const T* py = x + ty * ld + NT * fi_;
+        if constexpr (VEC) {
+            const VT vx = *reinterpret_cast<const VT*>(px);
+            const VT vy = *reinterpret_cast<const VT*>(py);
 #pragma unroll
-        for (int u = 0; u < kUnroll; ++u) {
-            info[u] = locate_frame(ft, q0 + 4 * u + kk, q_end);
-            const T* px = x + info[u].t * ld + fi_;
-            const T* py = x + (info[u].t + (info[u].in_x0 ? lag : 0)) * ld + fi_;
+            for (int a = 0; a < NT; ++a) { rx[a] = vx[a]; ry[a] = vy[a]; }
+        } else {
 #pragma unroll
             for (int a = 0; a < NT; ++a) {
-                rx[u][a] = (info[u].valid && fok[a]) ? px[16 * a] : (T)0;
-                ry[u][a] = (info[u].in_x0 && fok[a]) ? py[16 * a] : (T)0;
+                rx[a] = fok[a] ? px[a] : (T)0;
+                ry[a] = fok[a] ? py[a] : (T)0;
             }
         }
     };
 
-    if (q_begin < q_end) issue_loads(q_begin);
-    for (int64_t q0 = q_begin; q0 < q_end; q0 += 4 * kUnroll) {
-        // consume the prefetched group into fp64 operands
-        double za[kUnroll][NT], zb[kUnroll][NT], zy[kUnroll][NT];
-#pragma unroll
-        for (int u = 0; u < kUnroll; ++u) {
-            const double w = (info[u].in_x0 ? 1.0 : 0.0) + (info[u].in_yt ? 1.0 : 0.0);
+    int seg = 0;  // wave-uniform
+    int64_t q0 = q_begin;
+    while (q0 < q_end) {
+        while (seg + 1 < ft.n && q0 >= ft.prefix[seg + 1]) ++seg;
+        const int64_t s_start = ft.start[seg], s_stop = ft.stop[seg];
+        const int64_t q_hi = min(q_end, ft.prefix[seg + 1]);   // this wave's share of the segment
+        int64_t t = s_start + (q0 - ft.prefix[seg]) + kk;
+        T rx[NT], ry[NT];
+        double wx, wy;
+        load_group(t, s_start, s_stop, rx, ry, wx, wy);
+        for (; q0 < q_hi; q0 += 4) {
+            // consume the prefetched group into fp64 operands
+            double za[NT], zb[NT], zy[NT];
+            const double w = wx + wy;
 #pragma unroll
             for (int a = 0; a < NT; ++a) {
-                double vx = to_f64(rx[u][a]);
-                double vy = to_f64(ry[u][a]);
+                const double vx = to_f64(rx[a]);
+                const double vy = to_f64(ry[a]);
                 double cx = vx - shift[a];
                 double cy = vy - shift[a];
-                if (!(vx == vx) || !info[u].valid || !fok[a]) cx = 0.0;  // NaN -> column mean
-                if (!(vy == vy) || !info[u].in_x0 || !fok[a]) cy = 0.0;
-                za[u][a] = cx;
-                zy[u][a] = cy;
-                zb[u][a] = w * cx;
-                sx[a] += info[u].in_x0 ? cx : 0.0;
-                sy[a] += info[u].in_yt ? cx : 0.0;
+                if constexpr (!FINITE) {  // NaN -> column mean
+                    if (!(vx == vx)) cx = 0.0;
+                    if (!(vy == vy)) cy = 0.0;
+                }
+                if constexpr (!VEC) {
+                    if (!fok[a]) { cx = 0.0; cy = 0.0; }
+                }
+                za[a] = cx;
+                zy[a] = wx * cy;
+                zb[a] = w * cx;
+                if constexpr (HALF <= 0) ssum[a] = fma(wx, cx, ssum[a]);
+                if constexpr (HALF == 1) ssum[a] = fma(wy, cx, ssum[a]);
+                if constexpr (HALF < 0) ssum2[a] = fma(wy, cx, ssum2[a]);
             }
-        }
-        // next group's loads fly while the matrix cores work
-        if (q0 + 4 * kUnroll < q_end) issue_loads(q0 + 4 * kUnroll);
-#pragma unroll
-        for (int u = 0; u < kUnroll; ++u) {
+            // next group's loads fly while the matrix cores work
+            t += 4;
+            if (q0 + 4 < q_hi) load_group(t, s_start, s_stop, rx, ry, wx, wy);
 #pragma unroll
             for (int a = 0; a < NT; ++a) {
 #pragma unroll
                 for (int b = 0; b < NT; ++b)
-                    acc0t[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(za[u][a], zy[u][b], acc0t[a][b], 0, 0, 0);
+                    if (TS::template own_0t<HALF>(a))
+                        acc0t[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(za[a], zy[b], acc0t[a][b], 0, 0, 0);
 #pragma unroll
                 for (int b = a; b < NT; ++b)
-                    acc00[sym_index<NT>(a, b)] =
-                        __builtin_amdgcn_mfma_f64_16x16x4f64(za[u][a], zb[u][b], acc00[sym_index<NT>(a, b)], 0, 0, 0);
+                    if (TS::template own_00<HALF>(sym_index<NT>(a, b)))
+                        acc00[sym_index<NT>(a, b)] = __builtin_amdgcn_mfma_f64_16x16x4f64(
+                            za[a], zb[b], acc00[sym_index<NT>(a, b)], 0, 0, 0);
             }
         }
     }
 
-    // ---- workgroup reduction in fixed wave order, then one slab per workgroup ----
-    double* sums = red + S::kTiles * 256;  // [kWaves][2][NT][64]
+    // ---- workgroup reduction: waves of a half add their tiles in wave order ----
+    double* sums = red + S::kTiles * 256;  // [4][2][NT][64]
 #pragma unroll
     for (int a = 0; a < NT; ++a) {
-        sums[((wave * 2 + 0) * NT + a) * 64 + lane] = sx[a];
-        sums[((wave * 2 + 1) * NT + a) * 64 + lane] = sy[a];
+        if constexpr (HALF <= 0) sums[((red_wave * 2 + 0) * NT + a) * 64 + lane] = ssum[a];
+        if constexpr (HALF == 1) sums[((red_wave * 2 + 1) * NT + a) * 64 + lane] = ssum[a];
+        if constexpr (HALF < 0) sums[((red_wave * 2 + 1) * NT + a) * 64 + lane] = ssum2[a];
     }
-    for (int w = 0; w < kWaves; ++w) {
-        if (wave == w) {
+    for (int w = 0; w < 4; ++w) {
+        if (red_wave == w) {
 #pragma unroll
             for (int a = 0; a < NT; ++a)
 #pragma unroll
                 for (int b = 0; b < NT; ++b)
+                    if (TS::template own_0t<HALF>(a)) {
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int idx = ((a * NT + b) * 4 + r) * 64 + lane;
-                        red[idx] = (w == 0 ? 0.0 : red[idx]) + acc0t[a][b][r];
+                        for (int r = 0; r < 4; ++r) {
+                            const int idx = ((a * NT + b) * 4 + r) * 64 + lane;
+                            red[idx] = (w == 0 ? 0.0 : red[idx]) + acc0t[a][b][r];
+                        }
                     }
 #pragma unroll
             for (int s = 0; s < S::kSym; ++s)
+                if (TS::template own_00<HALF>(s)) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int idx = ((NT * NT + s) * 4 + r) * 64 + lane;
-                    red[idx] = (w == 0 ? 0.0 : red[idx]) + acc00[s][r];
+                    for (int r = 0; r < 4; ++r) {
+                        const int idx = ((NT * NT + s) * 4 + r) * 64 + lane;
+                        red[idx] = (w == 0 ? 0.0 : red[idx]) + acc00[s][r];
+                    }
                 }
         }
         __syncthreads();
     }
+}
+
+template <typename T, int NT, bool VEC, bool SPLIT, bool FINITE>
+__global__ __launch_bounds__(SPLIT ? 512 : 256, SPLIT ? 2 : 1) void cov_fused_kernel(
+    const T* __restrict__ x, int F, int64_t ld, FrameTab ft, const double* __restrict__ mu, int64_t frames_per_wave,
+    double* __restrict__ slabs) {
+    using S = CovShape<NT>;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    double* red = reinterpret_cast<double*>(smem_raw);  // [kTiles*256] then [4][2][NT][64]
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    if constexpr (SPLIT) {
+        if (wave < 4) cov_wave_body<T, NT, VEC, 0, FINITE>(x, F, ld, ft, mu, frames_per_wave, wave, 4, red, wave);
+        else cov_wave_body<T, NT, VEC, 1, FINITE>(x, F, ld, ft, mu, frames_per_wave, wave - 4, 4, red, wave - 4);
+    } else {
+        cov_wave_body<T, NT, VEC, -1, FINITE>(x, F, ld, ft, mu, frames_per_wave, wave, 4, red, wave);
+    }
     double* slab = slabs + (size_t)blockIdx.x * S::kSlab;
-    for (int i = tid; i < S::kTiles * 256; i += kThreads) slab[i] = red[i];
-    // column sums: element e = which*NT*16 + a*16 + f ; add over waves and the 4 frame groups
+    for (int i = tid; i < S::kTiles * 256; i += blockDim.x) slab[i] = red[i];
+    // column sums: element e = which*NT*16 + a*16 + i ; add over the 4 frame-waves and the 4 frame groups
+    const double* sums = red + S::kTiles * 256;
     if (tid < 2 * NT * 16) {
         const int which = tid / (NT * 16);
         const int a = (tid / 16) % NT;
         const int f = tid % 16;
         double acc = 0.0;
-        for (int w = 0; w < kWaves; ++w)
+        for (int w = 0; w < 4; ++w)
             for (int g = 0; g < 4; ++g) acc += sums[((w * 2 + which) * NT + a) * 64 + g * 16 + f];
         slab[S::kTiles * 256 + tid] = acc;
     }
 }
 
-// Adds the slabs in block order and scatters tiles into the moment block
+// Adds the slabs and scatters tiles into the moment block
 //   out = [M00 F*F][M0t F*F][sx F][sy F][T]      (raw, centred by `mu`, unscaled)
+// 1024 threads = 16 slab-groups x 64 elements; group g adds slabs g, g+16, ... and the 16
+// partial sums are added in group order (fixed order -> bitwise reproducible).
 template <int NT>
-__global__ void cov_reduce_kernel(const double* __restrict__ slabs, int n_slabs, int F, double pairs,
-                                  double* __restrict__ out) {
+__global__ __launch_bounds__(1024) void cov_reduce_kernel(const double* __restrict__ slabs, int n_slabs, int F,
+                                                         double pairs, double* __restrict__ out) {
     using S = CovShape<NT>;
-    const int e = blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= S::kSlab) return;
+    __shared__ double red[16][64];
+    const int io = threadIdx.x & 63, g = threadIdx.x >> 6;
+    const int e = blockIdx.x * 64 + io;
+    double part = 0.0;
+    if (e < S::kSlab)
+        for (int b = g; b < n_slabs; b += 16) part += slabs[(size_t)b * S::kSlab + e];
+    red[g][io] = part;
+    __syncthreads();
+    if (g != 0 || e >= S::kSlab) return;
     double acc = 0.0;
-    for (int b = 0; b < n_slabs; ++b) acc += slabs[(size_t)b * S::kSlab + e];
+    for (int k = 0; k < 16; ++k) acc += red[k][io];
     double* M00 = out;
     double* M0t = out + (size_t)F * F;
     double* sxy = M0t + (size_t)F * F;
@@ -229,14 +285,15 @@ __global__ void cov_reduce_kernel(const double* __restrict__ slabs, int n_slabs,
         const int lane = e & 63;
         const int row_in = (lane >> 4) + 4 * r;  // f64 MFMA C/D layout
         const int col_in = lane & 15;
+        // feature of (tile a, row i) is NT*i + a (see cov_fused_kernel)
         if (tile < NT * NT) {
-            const int row = 16 * (tile / NT) + row_in, col = 16 * (tile % NT) + col_in;
+            const int row = NT * row_in + tile / NT, col = NT * col_in + tile % NT;
             if (row < F && col < F) M0t[(size_t)row * F + col] = acc;
         } else {
             int s = tile - NT * NT, ti = 0;
             while (s >= NT - ti) { s -= NT - ti; ++ti; }
             const int tj = ti + s;
-            const int row = 16 * ti + row_in, col = 16 * tj + col_in;
+            const int row = NT * row_in + ti, col = NT * col_in + tj;
             if (row < F && col < F) {
                 M00[(size_t)row * F + col] = acc;
                 if (ti != tj) M00[(size_t)col * F + row] = acc;
@@ -245,7 +302,8 @@ __global__ void cov_reduce_kernel(const double* __restrict__ slabs, int n_slabs,
     } else {
         const int i = e - S::kTiles * 256;
         const int which = i / (NT * 16);
-        const int f = i % (NT * 16);
+        const int a = (i / 16) % NT, fi = i % 16;
+        const int f = NT * fi + a;
         if (f < F) sxy[(size_t)which * F + f] = acc;
     }
     if (e == 0) sxy[2 * (size_t)F] = pairs;
@@ -269,7 +327,7 @@ msm_status build_frametab(msm_ctx* ctx, int64_t n, const int64_t* h_start, const
                             "accumulate over several calls", MSM_SEG_INLINE);
         ft.start[ft.n] = a;
         ft.stop[ft.n] = b;
-        ft.prefix[ft.n + 1] = ft.prefix[ft.n] + (b - a);
+        ft.prefix[ft.n + 1] = ft.prefix[ft.n] + ((b - a) + kGroup - 1) / kGroup * kGroup;
         ft.pairs += (b - a) - lag;
         ++ft.n;
     }
@@ -280,26 +338,30 @@ msm_status build_frametab(msm_ctx* ctx, int64_t n, const int64_t* h_start, const
 
 template <typename T, int NT>
 msm_status launch_cov(msm_ctx* ctx, const T* x, int F, int64_t ld, const FrameTab& ft, const double* mu,
-                      double* d_out) {
+                      bool finite, double* d_out) {
     using S = CovShape<NT>;
     int blocks = ctx->n_cu;  // one 4-wave workgroup per CU: each wave owns a SIMD's matrix core
-    const int64_t groups = (ft.total + 4 * kUnroll - 1) / (4 * kUnroll);
+    const int64_t groups = ft.total / kGroup;
     const int64_t min_groups_per_wave = 4;
     if ((int64_t)blocks * kWaves * min_groups_per_wave > groups)
         blocks = (int)std::max<int64_t>(1, groups / (kWaves * min_groups_per_wave));
     int64_t fpw = (ft.total + (int64_t)blocks * kWaves - 1) / ((int64_t)blocks * kWaves);
-    fpw = (fpw + 4 * kUnroll - 1) / (4 * kUnroll) * (4 * kUnroll);
+    fpw = (fpw + kGroup - 1) / kGroup * kGroup;
     blocks = (int)((ft.total + fpw * kWaves - 1) / (fpw * kWaves));
     msm_status rs = msm_reserve_scratch(ctx, (size_t)blocks * S::kSlab * sizeof(double));
     if (rs != MSM_OK) return rs;
     const size_t lds = ((size_t)S::kTiles * 256 + (size_t)kWaves * 2 * NT * 64) * sizeof(double);
-    auto kern = cov_fused_kernel<T, NT>;
-    if (lds > 64 * 1024)
+    // vector path: every lane's NT features exist and its NT-element load is aligned
+    const bool vec = (NT != 3) && (F == 16 * NT) && (ld % NT == 0) && (((uintptr_t)x) % (NT * sizeof(T)) == 0);
+    constexpr bool kSplit = NT >= 3;
+    auto kern = vec ? (finite ? cov_fused_kernel<T, NT, true, kSplit, true> : cov_fused_kernel<T, NT, true, kSplit, false>)
+                    : (finite ? cov_fused_kernel<T, NT, false, kSplit, true> : cov_fused_kernel<T, NT, false, kSplit, false>);
+    if (lds > 48 * 1024)
         MSM_HIP(ctx, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(kern, dim3(blocks), dim3(kThreads), lds, ctx->stream, x, F, ld, ft, mu, fpw,
+    hipLaunchKernelGGL(kern, dim3(blocks), dim3(kSplit ? 512 : 256), lds, ctx->stream, x, F, ld, ft, mu, fpw,
                        (double*)ctx->scratch);
     MSM_CHECK_LAUNCH(ctx);
-    hipLaunchKernelGGL(cov_reduce_kernel<NT>, dim3(msm_ceil_div(S::kSlab, 256)), dim3(256), 0, ctx->stream,
+    hipLaunchKernelGGL(cov_reduce_kernel<NT>, dim3(msm_ceil_div(S::kSlab, 64)), dim3(1024), 0, ctx->stream,
                        (const double*)ctx->scratch, blocks, F, (double)ft.pairs, d_out);
     MSM_CHECK_LAUNCH(ctx);
     return MSM_OK;
@@ -307,11 +369,11 @@ msm_status launch_cov(msm_ctx* ctx, const T* x, int F, int64_t ld, const FrameTa
 
 template <typename T>
 msm_status dispatch_cov(msm_ctx* ctx, const T* x, int F, int64_t ld, const FrameTab& ft, const double* mu,
-                        double* d_out) {
-    if (F <= 16) return launch_cov<T, 1>(ctx, x, F, ld, ft, mu, d_out);
-    if (F <= 32) return launch_cov<T, 2>(ctx, x, F, ld, ft, mu, d_out);
-    if (F <= 48) return launch_cov<T, 3>(ctx, x, F, ld, ft, mu, d_out);
-    if (F <= 64) return launch_cov<T, 4>(ctx, x, F, ld, ft, mu, d_out);
+                        bool finite, double* d_out) {
+    if (F <= 16) return launch_cov<T, 1>(ctx, x, F, ld, ft, mu, finite, d_out);
+    if (F <= 32) return launch_cov<T, 2>(ctx, x, F, ld, ft, mu, finite, d_out);
+    if (F <= 48) return launch_cov<T, 3>(ctx, x, F, ld, ft, mu, finite, d_out);
+    if (F <= 64) return launch_cov<T, 4>(ctx, x, F, ld, ft, mu, finite, d_out);
     return msm_fail(ctx, MSM_ERR_UNSUPPORTED, "msm_lagged_moments: F=%d > 64 not supported yet", F);
 }
 
@@ -321,7 +383,7 @@ extern "C" {
 
 msm_status msm_lagged_moments(msm_ctx* ctx, const void* d_x, msm_dtype dtype, int64_t n, int F, int64_t ld,
                               const int64_t* h_seg_start, const int64_t* h_seg_stop, int n_seg, int lag,
-                              const double* d_shift, double* d_moments) {
+                              const double* d_shift, int assume_finite, double* d_moments) {
     if (!ctx) return MSM_ERR_INVALID;
     MSM_REQUIRE(ctx, n >= 0 && F >= 1 && ld >= F, "msm_lagged_moments: need n >= 0, F >= 1, ld >= F");
     MSM_REQUIRE(ctx, dtype == MSM_F32 || dtype == MSM_F64, "msm_lagged_moments: bad dtype");
@@ -333,8 +395,9 @@ msm_status msm_lagged_moments(msm_ctx* ctx, const void* d_x, msm_dtype dtype, in
         MSM_HIP(ctx, hipMemsetAsync(d_moments, 0, ((size_t)2 * F * F + 2 * F + 1) * sizeof(double), ctx->stream));
         return MSM_OK;
     }
-    if (dtype == MSM_F32) return dispatch_cov<float>(ctx, (const float*)d_x, F, ld, ft, d_shift, d_moments);
-    return dispatch_cov<double>(ctx, (const double*)d_x, F, ld, ft, d_shift, d_moments);
+    if (dtype == MSM_F32)
+        return dispatch_cov<float>(ctx, (const float*)d_x, F, ld, ft, d_shift, assume_finite != 0, d_moments);
+    return dispatch_cov<double>(ctx, (const double*)d_x, F, ld, ft, d_shift, assume_finite != 0, d_moments);
 }
 
 }  // extern "C"

@@ -38,10 +38,49 @@ __device__ __forceinline__ double block_sum(double v, JacobiShared* sh) {
     return sh->bc[0];
 }
 
+// Short-latency fp64 reciprocal / reciprocal square root: hardware seed plus two
+// Newton steps (the IEEE division / sqrt expansions are 3-4x longer dependent chains,
+// and the rotation set-up is the serial part of every Jacobi round).
+__device__ __forceinline__ double nr_rcp(double x) {
+    double r = __builtin_amdgcn_rcp(x);
+    r = fma(r, fma(-x, r, 1.0), r);
+    r = fma(r, fma(-x, r, 1.0), r);
+    return r;
+}
+__device__ __forceinline__ double nr_rsqrt(double x) {
+    double r = __builtin_amdgcn_rsq(x);
+    const double h = 0.5 * x;
+    r = r * fma(-h * r, r, 1.5);
+    r = r * fma(-h * r, r, 1.5);
+    return r;
+}
+
+// Jacobi rotation annihilating a_pq:  t = sgn(a) b / (|a| + sqrt(a^2 + b^2)) with
+// a = (a_qq - a_pp)/2, b = a_pq;  c = 1/sqrt(1 + t^2), s = t c  (so c^2 + s^2 = 1 to
+// rounding, which is what keeps V orthogonal).
+__device__ __forceinline__ void jacobi_rotation(double app, double aqq, double apq, double& c, double& s) {
+    c = 1.0; s = 0.0;
+    if (apq == 0.0) return;
+    const double a = 0.5 * (aqq - app);
+    const double h2 = fma(a, a, apq * apq);
+    if (!(h2 > 1e-300) || !(h2 < 1e300)) return;  // degenerate scale: skip this pivot
+    const double h = h2 * nr_rsqrt(h2);
+    const double t = (a >= 0.0 ? apq : -apq) * nr_rcp(fabs(a) + h);
+    c = nr_rsqrt(fma(t, t, 1.0));
+    s = t * c;
+}
+
 // A (n x n, row stride ld, symmetric) -> diagonal; V -> eigenvectors in columns.
 // Returns the number of sweeps used (uniform across the block).
+//
+// Work split: a wave owns pivots i = wave, wave + n_waves, ... of the round and its
+// lanes walk the row (then column) index, so (p, q, c, s) are wave-uniform values kept
+// in registers between the two phases: no parameter exchange, two barriers per round.
+// A wave may form its rotation right after the previous round's barrier because rows
+// p, q (which hold a_pp, a_qq, a_pq) are touched by no other pivot of the round.
 __device__ int jacobi_eigh(double* A, double* V, int n, int ld, JacobiShared* sh, int max_sweeps) {
     const int tid = threadIdx.x, nt = blockDim.x;
+    const int lane = tid & 63, wave = tid >> 6, n_waves = nt >> 6;
     for (int i = tid; i < n * n; i += nt) V[(i / n) * ld + (i % n)] = (i / n == i % n) ? 1.0 : 0.0;
     __syncthreads();
     if (n < 2) return 0;
@@ -50,11 +89,11 @@ __device__ int jacobi_eigh(double* A, double* V, int n, int ld, JacobiShared* sh
     int sweep = 0;
     for (; sweep < max_sweeps; ++sweep) {
         double off = 0.0, dia = 0.0;
-        for (int i = tid; i < n * n; i += nt) {
-            const int r = i / n, c = i % n;
-            const double v = A[r * ld + c];
-            if (r == c) dia = fma(v, v, dia); else off = fma(v, v, off);
-        }
+        for (int r = wave; r < n; r += n_waves)
+            for (int c = lane; c < n; c += 64) {
+                const double v = A[r * ld + c];
+                if (r == c) dia = fma(v, v, dia); else off = fma(v, v, off);
+            }
         off = block_sum(off, sh);
         dia = block_sum(dia, sh);
         // converged when ||off||_F <= n*eps*||A||_F: rounding of the rotations themselves
@@ -63,55 +102,46 @@ __device__ int jacobi_eigh(double* A, double* V, int n, int ld, JacobiShared* sh
         const double tol = (double)n * 2.220446049250313e-16;
         if (off <= tol * tol * (dia + off) || off == 0.0) break;
         for (int round = 0; round < npad - 1; ++round) {
-            if (tid < m) {
+            // rows: A <- J' A   (rotation parameters parked in LDS for the column phase)
+#pragma unroll 1
+            for (int i = wave; i < m; i += n_waves) {
                 int a, b;
-                if (tid == 0) { a = npad - 1; b = round; }
-                else { a = (round + tid) % (npad - 1); b = (round - tid + (npad - 1)) % (npad - 1); }
+                if (i == 0) { a = npad - 1; b = round; }
+                else { a = (round + i) % (npad - 1); b = (round - i + (npad - 1)) % (npad - 1); }
                 const int p = min(a, b), q = max(a, b);
-                double c = 1.0, s = 0.0;
-                if (q < n) {
-                    const double apq = A[p * ld + q];
-                    if (apq != 0.0) {
-                        const double app = A[p * ld + p], aqq = A[q * ld + q];
-                        const double theta = (aqq - app) / (2.0 * apq);
-                        const double t = (theta >= 0.0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(fma(theta, theta, 1.0)));
-                        c = 1.0 / sqrt(fma(t, t, 1.0));
-                        s = t * c;
-                    }
+                if (q >= n) continue;  // padding pivot (odd n)
+                double c, s;
+                jacobi_rotation(A[p * ld + p], A[q * ld + q], A[p * ld + q], c, s);
+                if (lane == 0) { sh->c[i] = c; sh->s[i] = s; }
+                double* rp = A + p * ld;
+                double* rq = A + q * ld;
+                for (int j = lane; j < n; j += 64) {
+                    const double ap = rp[j], aq = rq[j];
+                    rp[j] = c * ap - s * aq;
+                    rq[j] = s * ap + c * aq;
                 }
-                sh->c[tid] = c; sh->s[tid] = s; sh->p[tid] = p; sh->q[tid] = q;
             }
             __syncthreads();
-            // rows: A <- J' A
-            for (int e = tid; e < m * n; e += nt) {
-                const int i = e / n, j = e - i * n;
-                const int q = sh->q[i];
+            // columns: A <- A J, V <- V J; the pivot is annihilated exactly
+#pragma unroll 1
+            for (int i = wave; i < m; i += n_waves) {
+                int a, b;
+                if (i == 0) { a = npad - 1; b = round; }
+                else { a = (round + i) % (npad - 1); b = (round - i + (npad - 1)) % (npad - 1); }
+                const int p = min(a, b), q = max(a, b);
                 if (q >= n) continue;
-                const int p = sh->p[i];
                 const double c = sh->c[i], s = sh->s[i];
-                const double ap = A[p * ld + j], aq = A[q * ld + j];
-                A[p * ld + j] = c * ap - s * aq;
-                A[q * ld + j] = s * ap + c * aq;
-            }
-            __syncthreads();
-            // columns: A <- A J, V <- V J
-            for (int e = tid; e < 2 * m * n; e += nt) {
-                const int which = e / (m * n);
-                const int e2 = e - which * m * n;
-                const int i = e2 / n, r = e2 - i * n;
-                const int q = sh->q[i];
-                if (q >= n) continue;
-                const int p = sh->p[i];
-                const double c = sh->c[i], s = sh->s[i];
-                double* M = which ? V : A;
-                const double mp = M[r * ld + p], mq = M[r * ld + q];
-                M[r * ld + p] = c * mp - s * mq;
-                M[r * ld + q] = s * mp + c * mq;
-            }
-            __syncthreads();
-            if (tid < m && sh->q[tid] < n) {  // the pivot is annihilated exactly
-                A[sh->p[tid] * ld + sh->q[tid]] = 0.0;
-                A[sh->q[tid] * ld + sh->p[tid]] = 0.0;
+                for (int r = lane; r < n; r += 64) {
+                    const double ap = A[r * ld + p], aq = A[r * ld + q];
+                    const double vp = V[r * ld + p], vq = V[r * ld + q];
+                    double np_ = c * ap - s * aq, nq_ = s * ap + c * aq;
+                    if (r == p) nq_ = 0.0;
+                    if (r == q) np_ = 0.0;
+                    A[r * ld + p] = np_;
+                    A[r * ld + q] = nq_;
+                    V[r * ld + p] = c * vp - s * vq;
+                    V[r * ld + q] = s * vp + c * vq;
+                }
             }
             __syncthreads();
         }
@@ -147,22 +177,42 @@ __device__ void canonical_signs(double* M, int n, int ncols, int ld) {
     __syncthreads();
 }
 
-struct TicaWork {  // global scratch, each n*ld doubles unless noted
-    double *C00, *C0t, *A, *V, *L, *tmp, *ev /*n*/, *mean /*n*/;
-    int* order;  // n
+struct TicaWork {  // global scratch: four n*ld matrices, then ev[n], mean[n], isc[n], order[n]
+    double *A, *V, *B1, *B2, *ev, *mean, *isc;
+    int* order;
 };
+
+// C[i][j] = sum_k opA(i,k) * B[k][j]   (opA = A or A'), i < rows, j < cols, k < inner
+__device__ void small_mm(double* C, const double* A, bool transA, const double* B, int rows, int cols, int inner,
+                         int ld) {
+    for (int e = threadIdx.x; e < rows * cols; e += blockDim.x) {
+        const int i = e / cols, j = e - i * cols;
+        double a = 0.0;
+        if (transA)
+            for (int k = 0; k < inner; ++k) a = fma(A[k * ld + i], B[k * ld + j], a);
+        else
+            for (int k = 0; k < inner; ++k) a = fma(A[i * ld + k], B[k * ld + j], a);
+        C[i * ld + j] = a;
+    }
+    __syncthreads();
+}
 
 // moments = [M00 F*F][M0t F*F][sx F][sy F][T]   (centred by shift, unscaled)
 // scale   = per-feature divisor applied to the centred data (NULL -> 1)
+// lds_mats: how many of {A, V, B1, B2} live in LDS (4, 2 or 0)
 __global__ __launch_bounds__(kEigThreads) void tica_solve_kernel(
     const double* __restrict__ mom, const double* __restrict__ scale, int n, int ld, double epsilon, int kinetic_map,
-    TicaWork wk, int use_lds, double* __restrict__ out_eig, double* __restrict__ out_W, double* __restrict__ out_mean,
+    TicaWork wk, int lds_mats, double* __restrict__ out_eig, double* __restrict__ out_W, double* __restrict__ out_mean,
     int* __restrict__ out_rank) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     __shared__ JacobiShared sh;
     const int tid = threadIdx.x, nt = blockDim.x;
-    double* A = use_lds ? reinterpret_cast<double*>(smem_raw) : wk.A;
-    double* V = use_lds ? A + (size_t)n * ld : wk.V;
+    double* lds = reinterpret_cast<double*>(smem_raw);
+    const size_t mat = (size_t)n * ld;
+    double* A = lds_mats >= 2 ? lds : wk.A;
+    double* V = lds_mats >= 2 ? lds + mat : wk.V;
+    double* B1 = lds_mats >= 4 ? lds + 2 * mat : wk.B1;
+    double* B2 = lds_mats >= 4 ? lds + 3 * mat : wk.B2;
 
     const double* M00 = mom;
     const double* M0t = mom + (size_t)n * n;
@@ -178,19 +228,17 @@ __global__ __launch_bounds__(kEigThreads) void tica_solve_kernel(
     }
     for (int i = tid; i < n; i += nt) {
         const double is = scale ? 1.0 / scale[i] : 1.0;
+        wk.isc[i] = is;
         wk.mean[i] = (sx[i] + sy[i]) / w * is;
         out_mean[i] = wk.mean[i];
     }
     __syncthreads();
     for (int e = tid; e < n * n; e += nt) {
         const int i = e / n, j = e - i * n;
-        const double isi = scale ? 1.0 / scale[i] : 1.0, isj = scale ? 1.0 / scale[j] : 1.0;
+        const double ss = wk.isc[i] * wk.isc[j];
         const double mm = wk.mean[i] * wk.mean[j];
-        const double c00 = 0.5 * (M00[e] + M00[j * n + i]) / w * isi * isj - mm;
-        const double c0t = (M0t[e] + M0t[j * n + i]) / w * isi * isj - mm;
-        wk.C00[i * ld + j] = c00;
-        wk.C0t[i * ld + j] = c0t;
-        A[i * ld + j] = c00;
+        A[i * ld + j] = 0.5 * (M00[e] + M00[j * n + i]) / w * ss - mm;   // C00
+        B1[i * ld + j] = (M0t[e] + M0t[j * n + i]) / w * ss - mm;        // C0t
     }
     __syncthreads();
 
@@ -216,35 +264,24 @@ __global__ __launch_bounds__(kEigThreads) void tica_solve_kernel(
         for (int i = tid; i < n * n; i += nt) out_W[i] = 0.0;
         return;
     }
+    // L (in B2) = V[:, order[:rank]] with canonical signs, columns scaled by 1/sqrt(s)
     for (int e = tid; e < n * rank; e += nt) {
         const int i = e / rank, j = e - i * rank;
-        wk.L[i * ld + j] = V[i * ld + wk.order[j]];
+        B2[i * ld + j] = V[i * ld + wk.order[j]];
     }
     __syncthreads();
-    canonical_signs(wk.L, n, rank, ld);
+    canonical_signs(B2, n, rank, ld);
     for (int e = tid; e < n * rank; e += nt) {
         const int i = e / rank, j = e - i * rank;
-        wk.L[i * ld + j] /= sqrt(wk.ev[wk.order[j]]);
+        B2[i * ld + j] /= sqrt(wk.ev[wk.order[j]]);
     }
     __syncthreads();
-    // ---- Ct = L' C0t L ----
-    for (int e = tid; e < n * rank; e += nt) {
-        const int i = e / rank, j = e - i * rank;
-        double a = 0.0;
-        for (int k = 0; k < n; ++k) a = fma(wk.C0t[i * ld + k], wk.L[k * ld + j], a);
-        wk.tmp[i * ld + j] = a;
-    }
-    __syncthreads();
+    // ---- Ct = L' C0t L: A <- C0t L, V <- L' A, A <- sym(V) ----
+    small_mm(A, B1, false, B2, n, rank, n, ld);
+    small_mm(V, B2, true, A, rank, rank, n, ld);
     for (int e = tid; e < rank * rank; e += nt) {
         const int i = e / rank, j = e - i * rank;
-        double a = 0.0;
-        for (int k = 0; k < n; ++k) a = fma(wk.L[k * ld + i], wk.tmp[k * ld + j], a);
-        wk.C00[i * ld + j] = a;  // C00 no longer needed: holds Ct
-    }
-    __syncthreads();
-    for (int e = tid; e < rank * rank; e += nt) {
-        const int i = e / rank, j = e - i * rank;
-        A[i * ld + j] = 0.5 * (wk.C00[i * ld + j] + wk.C00[j * ld + i]);
+        A[i * ld + j] = 0.5 * (V[i * ld + j] + V[j * ld + i]);
     }
     __syncthreads();
     jacobi_eigh(A, V, rank, ld, &sh, 40);
@@ -256,16 +293,16 @@ __global__ __launch_bounds__(kEigThreads) void tica_solve_kernel(
         const int i = e / rank, j = e - i * rank;
         const int src = wk.order[j];
         double a = 0.0;
-        for (int k = 0; k < rank; ++k) a = fma(wk.L[i * ld + k], V[k * ld + src], a);
-        wk.tmp[i * ld + j] = a;
+        for (int k = 0; k < rank; ++k) a = fma(B2[i * ld + k], V[k * ld + src], a);
+        B1[i * ld + j] = a;
     }
     __syncthreads();
-    canonical_signs(wk.tmp, n, rank, ld);
+    canonical_signs(B1, n, rank, ld);
     for (int e = tid; e < n * n; e += nt) {
         const int i = e / n, j = e - i * n;
         double v = 0.0;
         if (j < rank) {
-            v = wk.tmp[i * ld + j];
+            v = B1[i * ld + j];
             if (kinetic_map) v *= wk.ev[wk.order[j]];
         }
         out_W[e] = v;
@@ -324,20 +361,23 @@ msm_status msm_tica_solve(msm_ctx* ctx, const double* d_moments, const double* d
     MSM_REQUIRE(ctx, d_moments && d_eigvals && d_coeffs && d_mean && d_rank, "msm_tica_solve: NULL pointer");
     const int ld = F | 1;  // odd stride
     const size_t mat = (size_t)F * ld;
-    const size_t need = (6 * mat + 2 * F) * sizeof(double) + (size_t)F * sizeof(int) + 64;
+    const size_t need = (4 * mat + 3 * F) * sizeof(double) + (size_t)F * sizeof(int) + 64;
     msm_status rs = msm_reserve_scratch(ctx, need);
     if (rs != MSM_OK) return rs;
     double* base = (double*)ctx->scratch;
     TicaWork wk;
-    wk.C00 = base; wk.C0t = base + mat; wk.A = base + 2 * mat; wk.V = base + 3 * mat; wk.L = base + 4 * mat;
-    wk.tmp = base + 5 * mat; wk.ev = base + 6 * mat; wk.mean = wk.ev + F; wk.order = (int*)(wk.mean + F);
-    const size_t lds = jacobi_lds_bytes(F, ld);
-    const int use_lds = lds <= 140 * 1024;
-    if (use_lds && lds > 48 * 1024)
+    wk.A = base; wk.V = base + mat; wk.B1 = base + 2 * mat; wk.B2 = base + 3 * mat;
+    wk.ev = base + 4 * mat; wk.mean = wk.ev + F; wk.isc = wk.mean + F; wk.order = (int*)(wk.isc + F);
+    const size_t lds_budget = 150 * 1024;
+    int lds_mats = 0;
+    if (4 * mat * sizeof(double) <= lds_budget) lds_mats = 4;
+    else if (2 * mat * sizeof(double) <= lds_budget) lds_mats = 2;
+    const size_t lds = (size_t)lds_mats * mat * sizeof(double);
+    if (lds > 48 * 1024)
         MSM_HIP(ctx, hipFuncSetAttribute((const void*)tica_solve_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                          (int)lds));
-    hipLaunchKernelGGL(tica_solve_kernel, dim3(1), dim3(kEigThreads), use_lds ? lds : 0, ctx->stream, d_moments,
-                       d_scale, F, ld, epsilon, kinetic_map, wk, use_lds, d_eigvals, d_coeffs, d_mean, d_rank);
+    hipLaunchKernelGGL(tica_solve_kernel, dim3(1), dim3(kEigThreads), lds, ctx->stream, d_moments, d_scale, F, ld,
+                       epsilon, kinetic_map, wk, lds_mats, d_eigvals, d_coeffs, d_mean, d_rank);
     MSM_CHECK_LAUNCH(ctx);
     return MSM_OK;
 }

@@ -69,17 +69,27 @@ __global__ __launch_bounds__(kThreads) void moments_partial_kernel(
 }
 
 // sums[3][F] = fixed-order sum over blocks; also records the shift used.
+// 1024 threads = 16 block-groups x 64 outputs: group g adds blocks g, g+16, ... (coalesced
+// over the outputs), then the 16 partial sums are added in group order.
 template <typename T>
-__global__ void moments_reduce_kernel(const double* __restrict__ partial, int n_blocks, int F,
-                                      const T* __restrict__ x, const double* __restrict__ shift_in,
-                                      double* __restrict__ sums, double* __restrict__ shift_out) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < 3 * F) {
-        double acc = 0.0;
-        for (int b = 0; b < n_blocks; ++b) acc += partial[(size_t)b * 3 * F + i];
-        sums[i] = acc;
+__global__ __launch_bounds__(1024) void moments_reduce_kernel(const double* __restrict__ partial, int n_blocks, int F,
+                                                             const T* __restrict__ x,
+                                                             const double* __restrict__ shift_in,
+                                                             double* __restrict__ sums, double* __restrict__ shift_out) {
+    __shared__ double red[16][64];
+    const int io = threadIdx.x & 63, g = threadIdx.x >> 6;
+    const int i = blockIdx.x * 64 + io;
+    double acc = 0.0;
+    if (i < 3 * F)
+        for (int b = g; b < n_blocks; b += 16) acc += partial[(size_t)b * 3 * F + i];
+    red[g][io] = acc;
+    __syncthreads();
+    if (g == 0 && i < 3 * F) {
+        double t = 0.0;
+        for (int k = 0; k < 16; ++k) t += red[k][io];
+        sums[i] = t;
     }
-    if (i < F && shift_out) {
+    if (g == 1 && i < F && shift_out) {
         double sh;
         if (shift_in) sh = shift_in[i];
         else { sh = ld_f64(x + i); if (sh != sh) sh = 0.0; }
@@ -177,6 +187,97 @@ __global__ __launch_bounds__(kThreads) void project_kernel(
     }
 }
 
+// ---------------------------------------------------------------------------
+// project on the fp64 matrix cores (d <= 16).
+//   Y' (16 x 16 frames) = W'' (16 x F) . Z' (F x 16 frames),  W'[f][c] = inv_sigma[f] * W[f][c]
+//   Z = x - mu (NaN -> 0), accumulator initialised with -sum_f m2[f] * W[f][c].
+// One MFMA = 4 features x (16 output columns x 16 frames).  The contraction order over
+// features is free, so k-step s = 4q + i is given features {16q + 4g + i : g = 0..3}: lane
+// (frame j = l & 15, g = l >> 4) then needs features 16q + 4g .. 16q + 4g + 3, one 16-byte
+// load per q.  Every 256-byte row is consumed whole across the four q loads.
+// ---------------------------------------------------------------------------
+typedef double v4f64 __attribute__((ext_vector_type(4)));
+constexpr int kPChunk = 64;  // features per register-resident chunk of W'
+
+template <typename T, bool VEC>
+__global__ __launch_bounds__(kThreads) void project_mfma_kernel(
+    const T* __restrict__ x, int64_t n, int F, int64_t ld, const double* __restrict__ mu,
+    const double* __restrict__ inv_sigma, const double* __restrict__ m2, const double* __restrict__ W, int d,
+    int64_t ldw, double* __restrict__ y, int64_t ldy) {
+    const int lane = threadIdx.x & 63;
+    const int j = lane & 15, g = lane >> 4;
+    const int64_t wave_id = ((int64_t)blockIdx.x * kThreads + threadIdx.x) >> 6;
+    const int64_t n_waves = ((int64_t)gridDim.x * kThreads) >> 6;
+    const int64_t n_groups = (n + 15) / 16;
+    const int n_chunks = (F + kPChunk - 1) / kPChunk;
+
+    // accumulator start: -(m2 . W[:, c]) for this lane's 4 output columns c = g + 4r
+    v4f64 acc0 = {0.0, 0.0, 0.0, 0.0};
+    if (m2) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int c = g + 4 * r;
+            double a = 0.0;
+            if (c < d)
+                for (int f = 0; f < F; ++f) a = fma(m2[f], W[(size_t)f * ldw + c], a);
+            acc0[r] = -a;
+        }
+    }
+    double wa[16], muv[16];
+    auto load_w = [&](int f0) {
+#pragma unroll
+        for (int s = 0; s < 16; ++s) {
+            const int f = f0 + 16 * (s >> 2) + 4 * g + (s & 3);
+            const bool ok = f < F && j < d;
+            wa[s] = ok ? inv_sigma[f] * W[(size_t)f * ldw + j] : 0.0;
+            muv[s] = f < F ? mu[f] : 0.0;
+        }
+    };
+    if (n_chunks == 1) load_w(0);
+
+    for (int64_t grp = wave_id; grp < n_groups; grp += n_waves) {
+        const int64_t t = grp * 16 + j;
+        const bool tok = t < n;
+        const T* row = x + (tok ? t : 0) * ld;
+        v4f64 acc = acc0;
+        for (int ch = 0; ch < n_chunks; ++ch) {
+            const int f0 = ch * kPChunk;
+            if (n_chunks > 1) load_w(f0);
+            double zv[16];
+            if constexpr (VEC) {
+                using VT = T __attribute__((ext_vector_type(4)));
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int f = f0 + 16 * q + 4 * g;
+                    VT v = {(T)0, (T)0, (T)0, (T)0};
+                    if (tok && f < F) v = *reinterpret_cast<const VT*>(row + f);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) zv[4 * q + i] = (double)v[i];
+                }
+            } else {
+#pragma unroll
+                for (int s = 0; s < 16; ++s) {
+                    const int f = f0 + 16 * (s >> 2) + 4 * g + (s & 3);
+                    zv[s] = (tok && f < F) ? (double)row[f] : 0.0;
+                }
+            }
+#pragma unroll
+            for (int s = 0; s < 16; ++s) {
+                double z = zv[s] - muv[s];
+                if (!(zv[s] == zv[s]) || !tok) z = 0.0;
+                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(wa[s], z, acc, 0, 0, 0);
+            }
+        }
+        if (tok) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int c = g + 4 * r;
+                if (c < d) y[t * ldy + c] = acc[r];
+            }
+        }
+    }
+}
+
 int pick_tf(int F) {
     int tf = 1;
     while (tf < F && tf < kThreads) tf <<= 1;
@@ -188,7 +289,7 @@ msm_status moments_partial_impl(msm_ctx* ctx, const T* x, int64_t n, int F, int6
                                 double* d_sums, double* d_shift_out) {
     const int tf = pick_tf(F);
     const int rp = kThreads / tf;
-    int blocks = (int)std::min<int64_t>((int64_t)ctx->n_cu * 8, std::max<int64_t>(1, n / (rp * 16)));
+    int blocks = (int)std::min<int64_t>((int64_t)ctx->n_cu * 4, std::max<int64_t>(1, n / (rp * 16)));
     const int64_t rows_per_block = (n + blocks - 1) / blocks;
     blocks = (int)((n + rows_per_block - 1) / rows_per_block);
     msm_status rs = msm_reserve_scratch(ctx, (size_t)blocks * 3 * F * sizeof(double));
@@ -197,7 +298,7 @@ msm_status moments_partial_impl(msm_ctx* ctx, const T* x, int64_t n, int F, int6
     hipLaunchKernelGGL(moments_partial_kernel<T>, dim3(blocks), dim3(kThreads), 3 * kThreads * sizeof(double),
                        ctx->stream, x, n, F, ld, d_shift, tf, rows_per_block, partial);
     MSM_CHECK_LAUNCH(ctx);
-    hipLaunchKernelGGL(moments_reduce_kernel<T>, dim3(msm_ceil_div(3 * F, 256)), dim3(256), 0, ctx->stream, partial,
+    hipLaunchKernelGGL(moments_reduce_kernel<T>, dim3(msm_ceil_div(3 * F, 64)), dim3(1024), 0, ctx->stream, partial,
                        blocks, F, x, d_shift, d_sums, d_shift_out);
     MSM_CHECK_LAUNCH(ctx);
     return MSM_OK;
@@ -254,9 +355,29 @@ msm_status msm_project(msm_ctx* ctx, const void* d_x, msm_dtype dtype, int64_t n
     MSM_REQUIRE(ctx, dtype == MSM_F32 || dtype == MSM_F64, "msm_project: bad dtype");
     if (n == 0) return MSM_OK;
     MSM_REQUIRE(ctx, d_x && d_mu && d_inv_sigma && d_w && d_y, "msm_project: NULL pointer");
+    if (d <= 16) {
+        const int64_t n_groups = (n + 15) / 16;
+        const int grid = (int)std::min<int64_t>((n_groups + 3) / 4, (int64_t)ctx->n_cu * 8);
+        const size_t esz = dtype == MSM_F32 ? 4 : 8;
+        const bool vec = (F % 16 == 0) && (ld % 4 == 0) && (((uintptr_t)d_x) % (4 * esz) == 0);
+#define MSM_PROJ(T, V)                                                                                         \
+        hipLaunchKernelGGL((project_mfma_kernel<T, V>), dim3(grid), dim3(kThreads), 0, ctx->stream, (const T*)d_x, n, \
+                           F, ld, d_mu, d_inv_sigma, d_mean2, d_w, d, ldw, d_y, ldy)
+        if (dtype == MSM_F32) { if (vec) MSM_PROJ(float, true); else MSM_PROJ(float, false); }
+        else { if (vec) MSM_PROJ(double, true); else MSM_PROJ(double, false); }
+#undef MSM_PROJ
+        MSM_CHECK_LAUNCH(ctx);
+        return MSM_OK;
+    }
     const size_t lds = ((size_t)kProjFrames * (kProjFT + 1) + (size_t)kProjFT * d) * sizeof(double);
     const int64_t n_tiles = (n + kProjFrames - 1) / kProjFrames;
     const int grid = (int)std::min<int64_t>(n_tiles, (int64_t)ctx->n_cu * 8);
+    if (lds > 48 * 1024) {
+        MSM_HIP(ctx, hipFuncSetAttribute((const void*)project_kernel<float>,
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        MSM_HIP(ctx, hipFuncSetAttribute((const void*)project_kernel<double>,
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    }
     if (dtype == MSM_F32)
         hipLaunchKernelGGL(project_kernel<float>, dim3(grid), dim3(kThreads), lds, ctx->stream, (const float*)d_x, n, F,
                            ld, d_mu, d_inv_sigma, d_mean2, d_w, d, ldw, d_y, ldy);

@@ -283,7 +283,7 @@ class Engine:
         return mean, std, cnt
 
     def lagged_moments(self, x: DeviceArray, lag: int, shift: DeviceArray, *, starts=None, stops=None,
-                       out: DeviceArray | None = None) -> DeviceArray:
+                       assume_finite: bool = False, out: DeviceArray | None = None) -> DeviceArray:
         """Raw reversible lagged moments [M00 | M0t | sx | sy | T] (2F^2+2F+1 f64)."""
         n, F = x.shape
         if starts is None:
@@ -291,7 +291,8 @@ class Engine:
         starts, stops = self._seg_ptrs(starts, stops)
         out = out if out is not None else self.empty((2 * F * F + 2 * F + 1,), np.float64)
         check(lib.msm_lagged_moments(self.handle, x.ptr, _dtype_code(x.dtype), n, F, F, starts.ctypes.data,
-                                     stops.ctypes.data, len(starts), int(lag), shift.ptr, out.ptr), self.handle)
+                                     stops.ctypes.data, len(starts), int(lag), shift.ptr, int(bool(assume_finite)),
+                                     out.ptr), self.handle)
         return out
 
     def tica_solve(self, moments: DeviceArray, F: int, *, scale: DeviceArray | None = None,
