@@ -227,6 +227,52 @@ msm_status msm_kmeans_assign(msm_ctx* ctx, const void* d_x, msm_dtype dtype, int
                              const double* d_mean, const double* d_std,
                              int32_t* d_labels, double* d_mindist);
 
+/* ---- k-means fit (Lloyd) ------------------------------------------------
+ * Replaces the estimator.fit of _KMeansDiscretizer.fit (S/analysis/discretize.py:
+ * 458-469, sklearn KMeans / MiniBatchKMeans) and of cluster_microstates
+ * (S/markov_state_model/clustering.py:605-609, deeptime KMeans.fit_fetch).
+ * Bit-level parity with those RNG-driven fits is not attainable (SURVEY.md hard
+ * part 2): the contract is (a) assignment parity given identical centres
+ * (msm_kmeans_assign), (b) inertia no worse than the reference's, (c) run-to-run
+ * and shard-count independence of the result for a fixed seed.
+ *
+ * Initial centres: k frames drawn by stratified sampling along the time axis
+ * (frame floor((j + u_j) n / k), u_j = splitmix64(seed, j)), whitened like the data.
+ * Iteration: assign (same arithmetic as msm_kmeans_assign) + accumulate member sums
+ * in 64-bit fixed point (integer atomics: order independent, exact across shards),
+ * then centres = sums / counts; empty clusters keep their centre.
+ *
+ * d_state: 8 doubles on the device = {scale, inv_scale, absmax, shift2, tol2, done,
+ * n_iter, inertia}.  Iterations after convergence (shift2 <= tol2) are no-ops, so a
+ * fixed launch sequence (or a captured graph) needs no host round trip.
+ *
+ * msm_kmeans_fit        = begin + max_iter x (accumulate + update) on one device.
+ * msm_kmeans_fit_begin  computes the fixed-point scale from max|z| and n_total (the
+ *                       frame count over ALL shards) and, if init_centers != 0, the
+ *                       initial centres.  Shards then all-reduce MIN of state[0].
+ * msm_kmeans_accumulate adds this shard's member sums / counts into d_sums int64 [k*d],
+ *                       d_counts int64 [k] (caller zeroes them; all-reduce SUM across shards).
+ * msm_kmeans_update     centres <- sums/counts, shift2, done, n_iter; clear != 0 zeroes
+ *                       the accumulators for the next iteration. */
+msm_status msm_kmeans_fit(msm_ctx* ctx, const void* d_x, msm_dtype dtype, int64_t n, int d, int64_t ld,
+                          const double* d_mean, const double* d_std, int k, uint64_t seed,
+                          int init_centers, int max_iter, double tol2, double* d_centers,
+                          double* d_state);
+msm_status msm_kmeans_fit_begin(msm_ctx* ctx, const void* d_x, msm_dtype dtype, int64_t n, int d,
+                                int64_t ld, const double* d_mean, const double* d_std, int k,
+                                uint64_t seed, int init_centers, double n_total, double tol2,
+                                double* d_centers, double* d_state);
+msm_status msm_kmeans_accumulate(msm_ctx* ctx, const void* d_x, msm_dtype dtype, int64_t n, int d,
+                                 int64_t ld, const double* d_centers, int k, const double* d_mean,
+                                 const double* d_std, const double* d_state, int64_t* d_sums,
+                                 int64_t* d_counts);
+msm_status msm_kmeans_update(msm_ctx* ctx, int64_t* d_sums, int64_t* d_counts, int k, int d,
+                             double* d_centers, double* d_state, int clear);
+
+/* d_out[0] = sum of d_v[0..n) with a fixed-order two-level reduction (inertia =
+ * sum of msm_kmeans_assign's d_mindist; clustering.py:391-392). */
+msm_status msm_sum_f64(msm_ctx* ctx, const double* d_v, int64_t n, double* d_out);
+
 #ifdef __cplusplus
 }
 #endif

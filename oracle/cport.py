@@ -40,6 +40,9 @@ def _load():
         _lib.oracle_kmeans_assign.argtypes = [
             C.c_void_p, C.c_int64, C.c_int, C.c_int64, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
             C.c_void_p, C.c_void_p]
+        _lib.oracle_kmeans_fit.restype = C.c_int
+        _lib.oracle_kmeans_fit.argtypes = [C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_uint64, C.c_int, C.c_double,
+                                           C.c_double, C.c_void_p, C.c_void_p]
     return _lib
 
 
@@ -93,3 +96,15 @@ def kmeans_assign(x, centers, mean=None, std=None, want_mindist=False):
                              s.ctypes.data if s is not None else None, labels.ctypes.data,
                              md.ctypes.data if md is not None else None)
     return (labels, md) if want_mindist else labels
+
+
+def kmeans_fit(xz, k, seed=0, max_iter=50, tol2=0.0, n_total=None):
+    """Engine's Lloyd fit restated on the CPU -> (centers, n_iter, scale).  xz already whitened."""
+    lib = _load()
+    xz = np.ascontiguousarray(xz, np.float64)
+    n, d = xz.shape
+    centers = np.empty((k, d), np.float64)
+    scale = C.c_double()
+    it = lib.oracle_kmeans_fit(xz.ctypes.data, n, d, k, int(seed), int(max_iter), float(tol2),
+                               float(n if n_total is None else n_total), centers.ctypes.data, C.byref(scale))
+    return centers, int(it), float(scale.value)

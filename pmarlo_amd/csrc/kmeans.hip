@@ -111,6 +111,292 @@ __global__ __launch_bounds__(kThreads) void kmeans_assign_kernel(
     }
 }
 
+// ---------------------------------------------------------------------------
+// fit: Lloyd iterations = (assign + accumulate) kernel, then a tiny update kernel.
+//
+// Accumulation is in 64-bit FIXED POINT: z * 2^e is rounded to an integer and added
+// with integer atomics (LDS per workgroup, then global).  Integer addition commutes,
+// so centre sums are bitwise independent of scheduling and of the number of GPUs the
+// frames are spread over (shards all-reduce the int64 sums exactly) -- the property
+// the reference tests as "same seed -> same labels"
+// (tests/perf/test_msm_clustering_perf.py:241-258).  e is chosen from max|z| so that
+// n_total * max|z| * 2^e < 2^62; the quantisation (<= 2^-e, ~1e-11 for O(1) data at
+// 1e6 frames) is far below the k-means tolerance.
+// ---------------------------------------------------------------------------
+struct FitState {  // device-resident control block (doubles for easy host readback)
+    double scale;      // 2^e
+    double inv_scale;  // 2^-e
+    double absmax;
+    double shift2;     // sum ||c_new - c_old||^2 of the last update
+    double tol2;       // stop when shift2 <= tol2
+    double done;       // 1.0 once converged: later accumulate/update launches are no-ops
+    double n_iter;
+    double inertia;
+};
+
+__device__ __forceinline__ long long to_fixed(double v, double scale) { return __double2ll_rn(v * scale); }
+
+template <typename T>
+__global__ __launch_bounds__(kThreads) void absmax_kernel(const T* __restrict__ x, int64_t n, int d, int64_t ld,
+                                                         const double* __restrict__ mean,
+                                                         const double* __restrict__ stdv,
+                                                         unsigned long long* __restrict__ out_bits) {
+    double m = 0.0;
+    const int64_t total = n * d;
+    for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < total; i += (int64_t)gridDim.x * kThreads) {
+        const int64_t r = i / d;
+        const int f = (int)(i - r * d);
+        double v = (double)x[r * ld + f];
+        if (mean) v = (v - mean[f]) / stdv[f];
+        v = fabs(v);
+        if (v > m) m = v;  // NaN compares false: ignored
+    }
+    for (int off = 32; off > 0; off >>= 1) m = fmax(m, __shfl_down(m, off, 64));
+    // non-negative doubles order like their bit patterns
+    if ((threadIdx.x & 63) == 0) atomicMax(out_bits, (unsigned long long)__double_as_longlong(m));
+}
+
+__global__ void fit_scale_kernel(const unsigned long long* __restrict__ absmax_bits, double n_total, double tol2,
+                                 FitState* __restrict__ st) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    double amax = __longlong_as_double((long long)*absmax_bits);
+    if (!(amax > 0.0)) amax = 1.0;
+    // 2^e * n_total * amax < 2^62
+    int e = 61 - (int)ceil(log2(n_total * amax));
+    if (e > 60) e = 60;
+    if (e < -900) e = -900;
+    st->scale = ldexp(1.0, e);
+    st->inv_scale = ldexp(1.0, -e);
+    st->absmax = amax;
+    st->shift2 = 0.0;
+    st->tol2 = tol2;
+    st->done = 0.0;
+    st->n_iter = 0.0;
+    st->inertia = 0.0;
+}
+
+// centres[j] = whitened frame floor((j + u_j) * n / k), u_j = hash(seed, j) in [0, 1)
+template <typename T>
+__global__ void init_centers_kernel(const T* __restrict__ x, int64_t n, int d, int64_t ld,
+                                    const double* __restrict__ mean, const double* __restrict__ stdv, int k,
+                                    unsigned long long seed, double* __restrict__ centers) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= k * d) return;
+    const int j = i / d, f = i - j * d;
+    unsigned long long h = seed + 0x9E3779B97F4A7C15ull * (unsigned long long)(j + 1);  // splitmix64
+    h = (h ^ (h >> 30)) * 0xBF58476D1CE4E5B9ull;
+    h = (h ^ (h >> 27)) * 0x94D049BB133111EBull;
+    h ^= h >> 31;
+    const double u = (double)(h >> 11) * (1.0 / 9007199254740992.0);
+    int64_t t = (int64_t)(((double)j + u) * ((double)n / (double)k));
+    if (t >= n) t = n - 1;
+    double v = (double)x[t * ld + f];
+    if (mean) v = (v - mean[f]) / stdv[f];
+    centers[i] = v;
+}
+
+// assign + accumulate.  sums int64 [k][d] (fixed point), counts int64 [k]; LDS-privatised
+// when k*(d+1) 8-byte bins fit beside the centre tile, otherwise global atomics.
+template <typename T, int D, int R, bool LDS_ACC>
+__global__ __launch_bounds__(kThreads) void kmeans_accum_kernel(
+    const T* __restrict__ x, int64_t n, int d, int64_t ld, const double* __restrict__ centers, int k,
+    const double* __restrict__ mean, const double* __restrict__ stdv, int tile_k, const FitState* __restrict__ st,
+    unsigned long long* __restrict__ sums, unsigned long long* __restrict__ counts) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    if (st->done != 0.0) return;
+    double* cs = reinterpret_cast<double*>(smem_raw);  // [tile_k][D]
+    double* csq = cs + (size_t)tile_k * D;              // [tile_k]
+    unsigned long long* lsum = reinterpret_cast<unsigned long long*>(csq + tile_k);  // [k][d] (LDS_ACC)
+    unsigned long long* lcnt = lsum + (size_t)k * d;                                  // [k]
+    const int tid = threadIdx.x;
+    const double scale = st->scale;
+    if constexpr (LDS_ACC) {
+        for (int i = tid; i < k * (d + 1); i += kThreads) lsum[i] = 0ull;
+    }
+    const int64_t frames_per_block = (int64_t)kThreads * R;
+    const int64_t n_blocks = (n + frames_per_block - 1) / frames_per_block;
+    for (int64_t blk = blockIdx.x; blk < n_blocks; blk += gridDim.x) {
+        double z[R][D];
+        int64_t fidx[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            fidx[r] = blk * frames_per_block + (int64_t)r * kThreads + tid;
+            const bool ok = fidx[r] < n;
+            const T* row = x + (ok ? fidx[r] : 0) * ld;
+#pragma unroll
+            for (int f = 0; f < D; ++f) {
+                double v = 0.0;
+                if (f < d) {
+                    v = load_as_f64(row + f);
+                    if (mean) v = (v - mean[f]) / stdv[f];
+                }
+                z[r][f] = v;
+            }
+        }
+        double best[R];
+        int bidx[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) { best[r] = __builtin_inf(); bidx[r] = 0; }
+        for (int k0 = 0; k0 < k; k0 += tile_k) {
+            const int kt = min(tile_k, k - k0);
+            __syncthreads();
+            for (int i = tid; i < kt * D; i += kThreads) {
+                const int j = i / D, f = i - j * D;
+                cs[i] = f < d ? centers[(size_t)(k0 + j) * d + f] : 0.0;
+            }
+            __syncthreads();
+            for (int j = tid; j < kt; j += kThreads) {
+                double a = 0.0;
+#pragma unroll
+                for (int f = 0; f < D; ++f) a = fma(cs[j * D + f], cs[j * D + f], a);
+                csq[j] = a;
+            }
+            __syncthreads();
+#pragma unroll 2
+            for (int j = 0; j < kt; ++j) {
+                const double* c = cs + j * D;
+                double dot[R];
+#pragma unroll
+                for (int r = 0; r < R; ++r) dot[r] = 0.0;
+#pragma unroll
+                for (int f = 0; f < D; ++f) {
+                    const double cf = c[f];
+#pragma unroll
+                    for (int r = 0; r < R; ++r) dot[r] = fma(z[r][f], cf, dot[r]);
+                }
+                const double cq = csq[j];
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    const double dist = fma(-2.0, dot[r], cq);
+                    if (dist < best[r]) { best[r] = dist; bidx[r] = k0 + j; }
+                }
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            if (fidx[r] < n) {
+                unsigned long long* srow = (LDS_ACC ? lsum : sums) + (size_t)bidx[r] * d;
+#pragma unroll
+                for (int f = 0; f < D; ++f)
+                    if (f < d) atomicAdd(&srow[f], (unsigned long long)to_fixed(z[r][f], scale));
+                atomicAdd((LDS_ACC ? lcnt : counts) + bidx[r], 1ull);
+            }
+        }
+    }
+    if constexpr (LDS_ACC) {
+        __syncthreads();
+        for (int i = tid; i < k * d; i += kThreads)
+            if (lsum[i]) atomicAdd(&sums[i], lsum[i]);
+        for (int i = tid; i < k; i += kThreads)
+            if (lcnt[i]) atomicAdd(&counts[i], lcnt[i]);
+    }
+}
+
+// centres <- sums / counts (empty clusters keep their centre); shift2 = sum ||delta||^2;
+// done <- shift2 <= tol2.  One workgroup; sums/counts are cleared for the next iteration.
+__global__ __launch_bounds__(1024) void kmeans_update_kernel(unsigned long long* __restrict__ sums,
+                                                            unsigned long long* __restrict__ counts, int k, int d,
+                                                            double* __restrict__ centers, FitState* __restrict__ st,
+                                                            int clear) {
+    __shared__ double red[16];
+    if (st->done != 0.0) return;
+    const double inv_scale = st->inv_scale;
+    double acc = 0.0;
+    for (int i = threadIdx.x; i < k * d; i += blockDim.x) {
+        const int j = i / d;
+        const long long cnt = (long long)counts[j];
+        if (cnt > 0) {
+            const double c_new = (double)(long long)sums[i] * inv_scale / (double)cnt;
+            const double dlt = c_new - centers[i];
+            acc = fma(dlt, dlt, acc);
+            centers[i] = c_new;
+        }
+    }
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (clear) {
+        for (int i = threadIdx.x; i < k * d; i += blockDim.x) sums[i] = 0ull;
+        for (int i = threadIdx.x; i < k; i += blockDim.x) counts[i] = 0ull;
+    }
+    if (threadIdx.x == 0) {
+        double t = 0.0;
+        for (int i = 0; i < (int)(blockDim.x >> 6); ++i) t += red[i];
+        st->shift2 = t;
+        st->n_iter += 1.0;
+        if (t <= st->tol2) st->done = 1.0;
+    }
+}
+
+// inertia = sum(mindist) with a fixed-order two-level reduction
+__global__ __launch_bounds__(1024) void sum_partial_kernel(const double* __restrict__ v, int64_t n,
+                                                          double* __restrict__ partial) {
+    __shared__ double red[16];
+    double acc = 0.0;
+    const int64_t chunk = (n + gridDim.x - 1) / gridDim.x;
+    const int64_t a = (int64_t)blockIdx.x * chunk, b = min(a + chunk, n);
+    for (int64_t i = a + threadIdx.x; i < b; i += blockDim.x) acc += v[i];
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t = 0.0;
+        for (int i = 0; i < 16; ++i) t += red[i];
+        partial[blockIdx.x] = t;
+    }
+}
+__global__ void sum_final_kernel(const double* __restrict__ partial, int nb, double* __restrict__ out) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        double t = 0.0;
+        for (int i = 0; i < nb; ++i) t += partial[i];
+        *out = t;
+    }
+}
+
+template <typename T, int D, int R>
+msm_status launch_accum(msm_ctx* ctx, const T* x, int64_t n, int d, int64_t ld, const double* centers, int k,
+                        const double* mean, const double* stdv, const FitState* st, unsigned long long* sums,
+                        unsigned long long* counts) {
+    const size_t acc_bytes = (size_t)k * (d + 1) * sizeof(unsigned long long);
+    const bool lds_acc = acc_bytes <= 64 * 1024;
+    const size_t budget = lds_acc ? (size_t)(150 * 1024) - acc_bytes : (size_t)kCentreLdsBudget;
+    int tile_k = (int)std::min<size_t>(budget, (size_t)kCentreLdsBudget * 2) / ((D + 1) * (int)sizeof(double));
+    if (tile_k > k) tile_k = k;
+    const size_t lds = (size_t)tile_k * (D + 1) * sizeof(double) + (lds_acc ? acc_bytes : 0);
+    const int64_t frames_per_block = (int64_t)kThreads * R;
+    const int64_t n_blocks = (n + frames_per_block - 1) / frames_per_block;
+    const int per_cu = lds > 80 * 1024 ? 1 : 2;
+    const int grid = (int)std::min<int64_t>(n_blocks, (int64_t)ctx->n_cu * per_cu);
+    auto kern = lds_acc ? kmeans_accum_kernel<T, D, R, true> : kmeans_accum_kernel<T, D, R, false>;
+    if (lds > 48 * 1024)
+        MSM_HIP(ctx, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(kThreads), lds, ctx->stream, x, n, d, ld, centers, k, mean, stdv, tile_k,
+                       st, sums, counts);
+    MSM_CHECK_LAUNCH(ctx);
+    return MSM_OK;
+}
+
+template <typename T>
+msm_status dispatch_accum(msm_ctx* ctx, const T* x, int64_t n, int d, int64_t ld, const double* centers, int k,
+                          const double* mean, const double* stdv, const FitState* st, unsigned long long* sums,
+                          unsigned long long* counts) {
+#define MSM_ACC_CASE(DP, RR) \
+    if (d <= DP) return launch_accum<T, DP, RR>(ctx, x, n, d, ld, centers, k, mean, stdv, st, sums, counts)
+    MSM_ACC_CASE(2, 4);
+    MSM_ACC_CASE(4, 4);
+    MSM_ACC_CASE(6, 4);
+    MSM_ACC_CASE(8, 4);
+    MSM_ACC_CASE(10, 4);
+    MSM_ACC_CASE(12, 4);
+    MSM_ACC_CASE(16, 4);
+    MSM_ACC_CASE(24, 2);
+    MSM_ACC_CASE(32, 2);
+    MSM_ACC_CASE(48, 1);
+    MSM_ACC_CASE(64, 1);
+#undef MSM_ACC_CASE
+    return msm_fail(ctx, MSM_ERR_UNSUPPORTED, "k-means fit: d=%d > 64 not supported yet", d);
+}
+
 template <typename T, int D, int R>
 msm_status launch_assign(msm_ctx* ctx, const T* x, int64_t n, int d, int64_t ld, const double* centers,
                          int k, const double* mean, const double* stdv, int32_t* labels, double* mindist) {
@@ -166,6 +452,108 @@ msm_status msm_kmeans_assign(msm_ctx* ctx, const void* d_x, msm_dtype dtype, int
                                       d_mindist);
     return dispatch_assign<double>(ctx, (const double*)d_x, n, d, ld, d_centers, k, d_mean, d_std, d_labels,
                                    d_mindist);
+}
+
+
+msm_status msm_kmeans_fit_begin(msm_ctx* ctx, const void* d_x, msm_dtype dtype, int64_t n, int d, int64_t ld,
+                                const double* d_mean, const double* d_std, int k, uint64_t seed, int init_centers,
+                                double n_total, double tol2, double* d_centers, double* d_state) {
+    if (!ctx) return MSM_ERR_INVALID;
+    MSM_REQUIRE(ctx, n >= 1 && d >= 1 && d <= 64 && k >= 1 && ld >= d, "msm_kmeans_fit_begin: bad shape");
+    MSM_REQUIRE(ctx, !init_centers || n >= k, "msm_kmeans_fit_begin: fewer frames (%lld) than centres (%d)",
+                (long long)n, k);
+    MSM_REQUIRE(ctx, (d_mean == nullptr) == (d_std == nullptr), "msm_kmeans_fit_begin: mean/std must come together");
+    MSM_REQUIRE(ctx, d_x && d_centers && d_state, "msm_kmeans_fit_begin: NULL pointer");
+    MSM_REQUIRE(ctx, dtype == MSM_F32 || dtype == MSM_F64, "msm_kmeans_fit_begin: bad dtype");
+    MSM_REQUIRE(ctx, n_total >= (double)n && tol2 >= 0.0, "msm_kmeans_fit_begin: bad n_total / tol2");
+    // d_state doubles as scratch for the absmax bits (slot 2 = absmax)
+    unsigned long long* bits = (unsigned long long*)(d_state + 2);
+    MSM_HIP(ctx, hipMemsetAsync(bits, 0, sizeof(unsigned long long), ctx->stream));
+    const int grid = (int)std::min<int64_t>((n * d + kThreads * 8 - 1) / (kThreads * 8), (int64_t)ctx->n_cu * 8);
+    if (dtype == MSM_F32)
+        hipLaunchKernelGGL(absmax_kernel<float>, dim3(grid), dim3(kThreads), 0, ctx->stream, (const float*)d_x, n, d, ld,
+                           d_mean, d_std, bits);
+    else
+        hipLaunchKernelGGL(absmax_kernel<double>, dim3(grid), dim3(kThreads), 0, ctx->stream, (const double*)d_x, n, d,
+                           ld, d_mean, d_std, bits);
+    MSM_CHECK_LAUNCH(ctx);
+    hipLaunchKernelGGL(fit_scale_kernel, dim3(1), dim3(64), 0, ctx->stream, bits, n_total, tol2, (FitState*)d_state);
+    MSM_CHECK_LAUNCH(ctx);
+    if (init_centers) {
+        const int g2 = msm_ceil_div((int64_t)k * d, 256);
+        if (dtype == MSM_F32)
+            hipLaunchKernelGGL(init_centers_kernel<float>, dim3(g2), dim3(256), 0, ctx->stream, (const float*)d_x, n, d,
+                               ld, d_mean, d_std, k, (unsigned long long)seed, d_centers);
+        else
+            hipLaunchKernelGGL(init_centers_kernel<double>, dim3(g2), dim3(256), 0, ctx->stream, (const double*)d_x, n,
+                               d, ld, d_mean, d_std, k, (unsigned long long)seed, d_centers);
+        MSM_CHECK_LAUNCH(ctx);
+    }
+    return MSM_OK;
+}
+
+msm_status msm_kmeans_accumulate(msm_ctx* ctx, const void* d_x, msm_dtype dtype, int64_t n, int d, int64_t ld,
+                                 const double* d_centers, int k, const double* d_mean, const double* d_std,
+                                 const double* d_state, int64_t* d_sums, int64_t* d_counts) {
+    if (!ctx) return MSM_ERR_INVALID;
+    MSM_REQUIRE(ctx, n >= 0 && d >= 1 && k >= 1 && ld >= d, "msm_kmeans_accumulate: bad shape");
+    MSM_REQUIRE(ctx, (d_mean == nullptr) == (d_std == nullptr), "msm_kmeans_accumulate: mean/std must come together");
+    MSM_REQUIRE(ctx, dtype == MSM_F32 || dtype == MSM_F64, "msm_kmeans_accumulate: bad dtype");
+    if (n == 0) return MSM_OK;
+    MSM_REQUIRE(ctx, d_x && d_centers && d_state && d_sums && d_counts, "msm_kmeans_accumulate: NULL pointer");
+    if (dtype == MSM_F32)
+        return dispatch_accum<float>(ctx, (const float*)d_x, n, d, ld, d_centers, k, d_mean, d_std,
+                                     (const FitState*)d_state, (unsigned long long*)d_sums,
+                                     (unsigned long long*)d_counts);
+    return dispatch_accum<double>(ctx, (const double*)d_x, n, d, ld, d_centers, k, d_mean, d_std,
+                                  (const FitState*)d_state, (unsigned long long*)d_sums, (unsigned long long*)d_counts);
+}
+
+msm_status msm_kmeans_update(msm_ctx* ctx, int64_t* d_sums, int64_t* d_counts, int k, int d, double* d_centers,
+                             double* d_state, int clear) {
+    if (!ctx) return MSM_ERR_INVALID;
+    MSM_REQUIRE(ctx, k >= 1 && d >= 1, "msm_kmeans_update: bad shape");
+    MSM_REQUIRE(ctx, d_sums && d_counts && d_centers && d_state, "msm_kmeans_update: NULL pointer");
+    hipLaunchKernelGGL(kmeans_update_kernel, dim3(1), dim3(1024), 0, ctx->stream, (unsigned long long*)d_sums,
+                       (unsigned long long*)d_counts, k, d, d_centers, (FitState*)d_state, clear);
+    MSM_CHECK_LAUNCH(ctx);
+    return MSM_OK;
+}
+
+msm_status msm_kmeans_fit(msm_ctx* ctx, const void* d_x, msm_dtype dtype, int64_t n, int d, int64_t ld,
+                          const double* d_mean, const double* d_std, int k, uint64_t seed, int init_centers,
+                          int max_iter, double tol2, double* d_centers, double* d_state) {
+    if (!ctx) return MSM_ERR_INVALID;
+    MSM_REQUIRE(ctx, max_iter >= 0, "msm_kmeans_fit: max_iter must be >= 0");
+    msm_status rs = msm_kmeans_fit_begin(ctx, d_x, dtype, n, d, ld, d_mean, d_std, k, seed, init_centers, (double)n,
+                                         tol2, d_centers, d_state);
+    if (rs != MSM_OK) return rs;
+    const size_t acc_bytes = (size_t)k * (d + 1) * sizeof(unsigned long long);
+    rs = msm_reserve_scratch(ctx, acc_bytes);
+    if (rs != MSM_OK) return rs;
+    int64_t* sums = (int64_t*)ctx->scratch;
+    int64_t* counts = sums + (size_t)k * d;
+    MSM_HIP(ctx, hipMemsetAsync(sums, 0, acc_bytes, ctx->stream));
+    for (int it = 0; it < max_iter; ++it) {
+        rs = msm_kmeans_accumulate(ctx, d_x, dtype, n, d, ld, d_centers, k, d_mean, d_std, d_state, sums, counts);
+        if (rs != MSM_OK) return rs;
+        rs = msm_kmeans_update(ctx, sums, counts, k, d, d_centers, d_state, 1);
+        if (rs != MSM_OK) return rs;
+    }
+    return MSM_OK;
+}
+
+msm_status msm_sum_f64(msm_ctx* ctx, const double* d_v, int64_t n, double* d_out) {
+    if (!ctx) return MSM_ERR_INVALID;
+    MSM_REQUIRE(ctx, n >= 0 && d_out && (d_v || n == 0), "msm_sum_f64: bad arguments");
+    const int nb = (int)std::min<int64_t>(256, std::max<int64_t>(1, n / 4096));
+    msm_status rs = msm_reserve_scratch(ctx, (size_t)nb * sizeof(double));
+    if (rs != MSM_OK) return rs;
+    hipLaunchKernelGGL(sum_partial_kernel, dim3(nb), dim3(1024), 0, ctx->stream, d_v, n, (double*)ctx->scratch);
+    MSM_CHECK_LAUNCH(ctx);
+    hipLaunchKernelGGL(sum_final_kernel, dim3(1), dim3(64), 0, ctx->stream, (const double*)ctx->scratch, nb, d_out);
+    MSM_CHECK_LAUNCH(ctx);
+    return MSM_OK;
 }
 
 }  // extern "C"

@@ -344,6 +344,57 @@ class Engine:
         return labels
 
 
+    FIT_STATE_FIELDS = ("scale", "inv_scale", "absmax", "shift2", "tol2", "done", "n_iter", "inertia")
+
+    def kmeans_fit(self, x: DeviceArray, k: int, *, seed: int = 0, max_iter: int = 50, tol2: float = 0.0,
+                   mean: DeviceArray | None = None, std: DeviceArray | None = None,
+                   centers: DeviceArray | None = None) -> tuple[DeviceArray, DeviceArray]:
+        """Lloyd k-means on one device -> (centers [k,d] f64, state [8] f64).
+        Pass `centers` to start from given centres instead of the seeded stratified draw."""
+        n, d = x.shape
+        init = centers is None
+        centers = centers if centers is not None else self.empty((k, d), np.float64)
+        state = self.zeros((8,), np.float64)
+        check(lib.msm_kmeans_fit(self.handle, x.ptr, _dtype_code(x.dtype), n, d, d,
+                                 mean.ptr if mean is not None else None, std.ptr if std is not None else None,
+                                 int(k), int(seed) & (2**64 - 1), int(init), int(max_iter), float(tol2), centers.ptr,
+                                 state.ptr), self.handle)
+        return centers, state
+
+    def kmeans_fit_begin(self, x: DeviceArray, k: int, *, seed: int, n_total: int, tol2: float,
+                         mean: DeviceArray | None = None, std: DeviceArray | None = None,
+                         centers: DeviceArray | None = None, init_centers: bool = True):
+        n, d = x.shape
+        centers = centers if centers is not None else self.empty((k, d), np.float64)
+        state = self.zeros((8,), np.float64)
+        check(lib.msm_kmeans_fit_begin(self.handle, x.ptr, _dtype_code(x.dtype), n, d, d,
+                                       mean.ptr if mean is not None else None,
+                                       std.ptr if std is not None else None, int(k), int(seed) & (2**64 - 1),
+                                       int(bool(init_centers)), float(n_total), float(tol2), centers.ptr, state.ptr),
+              self.handle)
+        return centers, state
+
+    def kmeans_accumulate(self, x: DeviceArray, centers: DeviceArray, state: DeviceArray, sums: DeviceArray,
+                          counts: DeviceArray, *, mean: DeviceArray | None = None, std: DeviceArray | None = None):
+        n, d = x.shape
+        k = centers.shape[0]
+        check(lib.msm_kmeans_accumulate(self.handle, x.ptr, _dtype_code(x.dtype), n, d, d, centers.ptr, k,
+                                        mean.ptr if mean is not None else None,
+                                        std.ptr if std is not None else None, state.ptr, sums.ptr, counts.ptr),
+              self.handle)
+
+    def kmeans_update(self, sums: DeviceArray, counts: DeviceArray, centers: DeviceArray, state: DeviceArray,
+                      clear: bool = True):
+        k, d = centers.shape
+        check(lib.msm_kmeans_update(self.handle, sums.ptr, counts.ptr, k, d, centers.ptr, state.ptr, int(clear)),
+              self.handle)
+
+    def sum_f64(self, v: DeviceArray, out: DeviceArray | None = None) -> DeviceArray:
+        out = out if out is not None else self.empty((1,), np.float64)
+        check(lib.msm_sum_f64(self.handle, v.ptr, v.size, out.ptr), self.handle)
+        return out
+
+
 _ENGINES: dict[int, Engine] = {}
 
 

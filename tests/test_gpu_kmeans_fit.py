@@ -1,0 +1,101 @@
+"""HIP k-means fit: bit-level agreement with the engine's CPU restatement, run-to-run
+determinism, and inertia against the reference's sklearn fit (SURVEY.md hard part 2)."""
+
+from __future__ import annotations
+
+import numpy as np
+import pytest
+
+from oracle import cport, npport
+from tests import _gen
+
+pytestmark = pytest.mark.gpu
+
+
+def _fit(engine, X, k, seed=0, max_iter=30, tol2=0.0, mean=None, std=None):
+    xd = engine.to_device(X)
+    m = engine.to_device(mean, np.float64) if mean is not None else None
+    s = engine.to_device(std, np.float64) if std is not None else None
+    centers, state = engine.kmeans_fit(xd, k, seed=seed, max_iter=max_iter, tol2=tol2, mean=m, std=s)
+    return centers.to_host(), dict(zip(engine.FIT_STATE_FIELDS, state.to_host())), xd
+
+
+@pytest.mark.parametrize("n,d,k,dtype", [(20_000, 4, 100, np.float64), (50_000, 10, 50, np.float32),
+                                          (5_000, 2, 8, np.float64), (3_000, 24, 40, np.float32)])
+def test_fit_bit_exact_vs_restated_lloyd(engine, n, d, k, dtype):
+    X = _gen.correlated_series(n, d, seed=n % 13).astype(dtype)
+    got, st, _ = _fit(engine, X, k, seed=7, max_iter=6)
+    want, it, scale = cport.kmeans_fit(X.astype(np.float64), k, seed=7, max_iter=6)
+    assert st["scale"] == scale
+    np.testing.assert_array_equal(got, want)
+    assert st["n_iter"] == 6 == it
+
+
+def test_fit_with_whitening_matches_prewhitened(engine):
+    X = _gen.correlated_series(30_000, 6, seed=5).astype(np.float64) * 7.0 + 3.0
+    mean, std = X.mean(axis=0), X.std(axis=0, ddof=1)
+    got, st, _ = _fit(engine, X, 64, seed=3, max_iter=5, mean=mean, std=std)
+    want, _, _ = cport.kmeans_fit((X - mean) / std, 64, seed=3, max_iter=5)
+    np.testing.assert_array_equal(got, want)
+
+
+def test_fit_is_deterministic_and_seed_dependent(engine):
+    """tests/perf/test_msm_clustering_perf.py:241-258: same seed -> same result."""
+    X = _gen.correlated_series(200_000, 10, seed=1)
+    a, _, _ = _fit(engine, X, 200, seed=11, max_iter=10)
+    b, _, _ = _fit(engine, X, 200, seed=11, max_iter=10)
+    c, _, _ = _fit(engine, X, 200, seed=12, max_iter=10)
+    np.testing.assert_array_equal(a, b)
+    assert not np.array_equal(a, c)
+
+
+def test_fit_converges_and_stops(engine):
+    X, _ = _gen.gaussian_clusters(8, 2000, 3, seed=4)
+    rng = np.random.default_rng(0)
+    X = X[rng.permutation(X.shape[0])]
+    centers, st, xd = _fit(engine, X, 8, seed=0, max_iter=100, tol2=1e-20)
+    assert st["done"] == 1.0 and st["n_iter"] < 100
+    # converged centres are the member means of their own assignment
+    lab = engine.kmeans_assign(xd, engine.to_device(centers)).to_host()
+    for j in np.unique(lab):
+        np.testing.assert_allclose(centers[j], X[lab == j].mean(axis=0), atol=1e-9)
+
+
+@pytest.mark.parametrize("n,d,k", [(100_000, 4, 100), (200_000, 10, 500)])
+def test_fit_inertia_vs_reference_sklearn(engine, n, d, k):
+    """Contract (b): inertia no worse than the reference's estimator on the same data.
+    C2-like size runs the reference's KMeans(n_init=1 here for time) branch; the
+    C3-like size its MiniBatchKMeans branch (n*d >= 5e6 in the reference at 1M frames)."""
+    from sklearn.cluster import KMeans, MiniBatchKMeans
+
+    X = _gen.correlated_series(n, d, seed=1000).astype(np.float64)
+    mean, std = X.mean(axis=0), X.std(axis=0, ddof=1)
+    Xz = (X - mean) / std
+    centers, st, xd = _fit(engine, X, k, seed=0, max_iter=40, tol2=1e-4 * d * 1e-4, mean=mean, std=std)
+    md = engine.empty((n,), np.float64)
+    engine.kmeans_assign(xd, engine.to_device(centers), mean=engine.to_device(mean), std=engine.to_device(std),
+                         mindist=md)
+    inertia = float(engine.sum_f64(md).to_host()[0])
+    np.testing.assert_allclose(inertia, md.to_host().sum(), rtol=1e-12)
+    if n * d >= 2_000_000:
+        ref = MiniBatchKMeans(n_clusters=k, random_state=0).fit(Xz)
+    else:
+        ref = KMeans(n_clusters=k, random_state=0, n_init=1).fit(Xz)
+    ref_inertia = float(((Xz - ref.cluster_centers_[npport.kmeans_predict(Xz, ref.cluster_centers_)]) ** 2).sum())
+    assert inertia <= ref_inertia * 1.05, (inertia, ref_inertia)
+
+
+def test_accumulate_update_split_equals_fit(engine):
+    """The shard-wise API (accumulate on two halves, summed int64, one update) equals the
+    single-device fit bit for bit: what makes the multi-GPU fit shard-count independent."""
+    n, d, k = 40_000, 8, 64
+    X = _gen.correlated_series(n, d, seed=2).astype(np.float64)
+    want, _, _ = _fit(engine, X, k, seed=5, max_iter=4)
+    xa, xb = engine.to_device(X[: n // 3]), engine.to_device(X[n // 3:])
+    centers, state = engine.kmeans_fit_begin(engine.to_device(X), k, seed=5, n_total=n, tol2=0.0)
+    sums, counts = engine.zeros((k * d,), np.int64), engine.zeros((k,), np.int64)
+    for _ in range(4):
+        engine.kmeans_accumulate(xa, centers, state, sums, counts)
+        engine.kmeans_accumulate(xb, centers, state, sums, counts)
+        engine.kmeans_update(sums, counts, centers, state, clear=True)
+    np.testing.assert_array_equal(centers.to_host(), want)
