@@ -273,6 +273,58 @@ msm_status msm_kmeans_update(msm_ctx* ctx, int64_t* d_sums, int64_t* d_counts, i
  * sum of msm_kmeans_assign's d_mindist; clustering.py:391-392). */
 msm_status msm_sum_f64(msm_ctx* ctx, const double* d_v, int64_t n, double* d_out);
 
+/* ------------------------------------------------------------------ */
+/* MSM estimation: transition matrix, stationary distribution, ITS      */
+/* ------------------------------------------------------------------ */
+
+/* Count matrix -> transition matrix.  d_counts is int64 [k*k] (counts_are_f64 = 0)
+ * or float64 [k*k].  d_rowsum f64 [k] receives the row sums of the counts.
+ *  mode 0: T = C / rowsum, all-zero rows stay zero, full k x k
+ *          (_normalise_counts, S/analysis/discretize.py:678-682); d_diag_mass (may be
+ *          NULL) = trace(T)/k (discretize.py:1059-1062).
+ *  mode 1: ensure_connected_counts + MaximumLikelihoodMSM(reversible=False)
+ *          (S/utils/msm_utils.py:129-167, S/markov_state_model/_estimation.py:158-188):
+ *          active = states with rowsum + colsum > epsilon (ascending), C_active + alpha on
+ *          every cell, T_active = row-normalised.  T_active is written PACKED into the
+ *          top-left n_active x n_active corner of d_T with row stride k; d_active int32 [k]
+ *          lists the active states, d_inv_map int32 [k] maps state -> packed index or -1,
+ *          d_n_active int32 [1]. */
+msm_status msm_transition_matrix(msm_ctx* ctx, const void* d_counts, int counts_are_f64, int k, int mode,
+                                 double alpha, double epsilon, double* d_T, int32_t* d_active,
+                                 int32_t* d_inv_map, int32_t* d_n_active, double* d_rowsum,
+                                 double* d_diag_mass);
+
+/* T_full = identity with the active block of a mode-1 result embedded, pi_full = 0
+ * outside the active set (_estimation.py:174-181).  d_pi_active / d_pi_full may be NULL. */
+msm_status msm_embed_full(msm_ctx* ctx, const double* d_T_active, const double* d_pi_active,
+                          const int32_t* d_inv_map, int k, double* d_T_full, double* d_pi_full);
+
+/* Leading spectrum of `batch` row-stochastic matrices (matrix b at d_T + b*t_stride, row
+ * stride ld, order d_n[b] or n_max when d_n is NULL) by subspace iteration on T' with
+ * Rayleigh-Ritz (one workgroup per matrix; the lag scan batches its lags).
+ * Replaces deeptime stationary_distribution + eigenvalues(T, k) as used by
+ * _finalize_transition_and_stationary and _summarize_its_stats
+ * (S/markov_state_model/_its.py:543-604), and utils.safe_timescales (utils.py:17-57).
+ *   p        subspace size (<= 32; use n_its + 1 + guard vectors)
+ *   n_iter   iterations this call; init != 0 (re)starts from a seeded basis, init == 0
+ *            continues from the basis left in d_workspace by the previous call
+ *   d_ritz   f64 [batch][128] = {re[32] | im[32] | previous re[32] | previous im[32]},
+ *            Ritz values sorted by descending magnitude
+ *   d_change f64 [batch]: max relative change of the top n_watch Ritz values over the last
+ *            4 iterations -- the caller relaunches with init = 0 until it is small
+ *   d_pi     f64 [batch][pi_stride] stationary distribution (sum 1), or NULL
+ *   n_its>0: d_its_eig / d_its_ts f64 [batch][n_its]: the top (n_its+1) values re-sorted by
+ *            descending real part, first dropped, |real part| clipped to [1e-12, 1-1e-12],
+ *            t = -max(1, lag)/ln(.), lag = d_lags[b]; NaN padding when fewer exist
+ *   d_status int32 [batch]: 0, or the hqr failure index
+ * d_workspace must hold msm_spectrum_workspace_bytes(n_max, p, batch) bytes. */
+size_t msm_spectrum_workspace_bytes(int n_max, int p, int batch);
+msm_status msm_spectrum(msm_ctx* ctx, const double* d_T, int64_t t_stride, int ld, const int32_t* d_n,
+                        int n_max, int batch, int p, int n_iter, int init, uint64_t seed, int n_watch,
+                        void* d_workspace, double* d_ritz, double* d_pi, int64_t pi_stride,
+                        double* d_change, int32_t* d_status, int n_its, const double* d_lags,
+                        double* d_its_eig, double* d_its_ts);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,204 @@
+// Eigenvalues (and one eigenvector) of a small dense real NON-symmetric matrix:
+// elimination to Hessenberg form + Francis double-shift QR (the classical EISPACK
+// elmhes / hqr pair).  Used on the p x p Rayleigh-Ritz matrix of the subspace
+// iteration (p <= 32), i.e. a latency-bound epilogue; plain scalar code that
+// compiles for host (unit-tested on the CPU) and device.
+#pragma once
+#include <math.h>
+
+#ifdef __HIPCC__
+#define SE_HD __host__ __device__
+#else
+#define SE_HD
+#endif
+
+namespace small_eig {
+
+SE_HD inline double sign_of(double a, double b) { return b >= 0.0 ? fabs(a) : -fabs(a); }
+
+// a: n x n row-major with row stride ld (destroyed).  Returns 0 on success, >0 = the
+// index at which 60 QR iterations did not converge.
+SE_HD inline int eigenvalues(double* a, int n, int ld, double* wr, double* wi) {
+#define A_(i, j) a[(i) * ld + (j)]
+    // ---- elmhes ----
+    for (int m = 1; m < n - 1; ++m) {
+        double x = 0.0;
+        int i = m;
+        for (int j = m; j < n; ++j)
+            if (fabs(A_(j, m - 1)) > fabs(x)) { x = A_(j, m - 1); i = j; }
+        if (i != m) {
+            for (int j = m - 1; j < n; ++j) { double t = A_(i, j); A_(i, j) = A_(m, j); A_(m, j) = t; }
+            for (int j = 0; j < n; ++j) { double t = A_(j, i); A_(j, i) = A_(j, m); A_(j, m) = t; }
+        }
+        if (x != 0.0) {
+            for (i = m + 1; i < n; ++i) {
+                double y = A_(i, m - 1);
+                if (y != 0.0) {
+                    y /= x;
+                    A_(i, m - 1) = y;
+                    for (int j = m; j < n; ++j) A_(i, j) -= y * A_(m, j);
+                    for (int j = 0; j < n; ++j) A_(j, m) += y * A_(j, i);
+                }
+            }
+        }
+    }
+    for (int i = 2; i < n; ++i)
+        for (int j = 0; j < i - 1; ++j) A_(i, j) = 0.0;
+    // ---- hqr ----
+    double anorm = 0.0;
+    for (int i = 0; i < n; ++i)
+        for (int j = (i > 0 ? i - 1 : 0); j < n; ++j) anorm += fabs(A_(i, j));
+    int nn = n - 1;
+    double t = 0.0, p = 0.0, q = 0.0, r = 0.0;
+    while (nn >= 0) {
+        int its = 0, l;
+        do {
+            for (l = nn; l >= 1; --l) {
+                double s = fabs(A_(l - 1, l - 1)) + fabs(A_(l, l));
+                if (s == 0.0) s = anorm;
+                if (fabs(A_(l, l - 1)) + s == s) { A_(l, l - 1) = 0.0; break; }
+            }
+            double x = A_(nn, nn);
+            if (l == nn) {
+                wr[nn] = x + t;
+                wi[nn--] = 0.0;
+            } else {
+                double y = A_(nn - 1, nn - 1);
+                double w = A_(nn, nn - 1) * A_(nn - 1, nn);
+                if (l == nn - 1) {
+                    p = 0.5 * (y - x);
+                    q = p * p + w;
+                    double z = sqrt(fabs(q));
+                    x += t;
+                    if (q >= 0.0) {
+                        z = p + sign_of(z, p);
+                        wr[nn - 1] = wr[nn] = x + z;
+                        if (z != 0.0) wr[nn] = x - w / z;
+                        wi[nn - 1] = wi[nn] = 0.0;
+                    } else {
+                        wr[nn - 1] = wr[nn] = x + p;
+                        wi[nn] = z;
+                        wi[nn - 1] = -z;
+                    }
+                    nn -= 2;
+                } else {
+                    if (its == 60) return nn + 1;
+                    if (its == 10 || its == 20 || its == 30 || its == 40) {
+                        t += x;
+                        for (int i = 0; i <= nn; ++i) A_(i, i) -= x;
+                        const double s = fabs(A_(nn, nn - 1)) + fabs(A_(nn - 1, nn - 2));
+                        y = x = 0.75 * s;
+                        w = -0.4375 * s * s;
+                    }
+                    ++its;
+                    int m;
+                    for (m = nn - 2; m >= l; --m) {
+                        const double z = A_(m, m);
+                        r = x - z;
+                        double s = y - z;
+                        p = (r * s - w) / A_(m + 1, m) + A_(m, m + 1);
+                        q = A_(m + 1, m + 1) - z - r - s;
+                        r = A_(m + 2, m + 1);
+                        s = fabs(p) + fabs(q) + fabs(r);
+                        p /= s; q /= s; r /= s;
+                        if (m == l) break;
+                        const double u = fabs(A_(m, m - 1)) * (fabs(q) + fabs(r));
+                        const double v = fabs(p) * (fabs(A_(m - 1, m - 1)) + fabs(z) + fabs(A_(m + 1, m + 1)));
+                        if (u + v == v) break;
+                    }
+                    for (int i = m + 2; i <= nn; ++i) {
+                        A_(i, i - 2) = 0.0;
+                        if (i != m + 2) A_(i, i - 3) = 0.0;
+                    }
+                    for (int k = m; k <= nn - 1; ++k) {
+                        if (k != m) {
+                            p = A_(k, k - 1);
+                            q = A_(k + 1, k - 1);
+                            r = 0.0;
+                            if (k != nn - 1) r = A_(k + 2, k - 1);
+                            if ((x = fabs(p) + fabs(q) + fabs(r)) != 0.0) { p /= x; q /= x; r /= x; }
+                        }
+                        const double s = sign_of(sqrt(p * p + q * q + r * r), p);
+                        if (s != 0.0) {
+                            if (k == m) {
+                                if (l != m) A_(k, k - 1) = -A_(k, k - 1);
+                            } else {
+                                A_(k, k - 1) = -s * x;
+                            }
+                            p += s;
+                            x = p / s;
+                            y = q / s;
+                            const double z = r / s;
+                            q /= p;
+                            r /= p;
+                            for (int j = k; j <= nn; ++j) {
+                                p = A_(k, j) + q * A_(k + 1, j);
+                                if (k != nn - 1) { p += r * A_(k + 2, j); A_(k + 2, j) -= p * z; }
+                                A_(k + 1, j) -= p * y;
+                                A_(k, j) -= p * x;
+                            }
+                            const int mmin = nn < k + 3 ? nn : k + 3;
+                            for (int i = l; i <= mmin; ++i) {
+                                p = x * A_(i, k) + y * A_(i, k + 1);
+                                if (k != nn - 1) { p += z * A_(i, k + 2); A_(i, k + 2) -= p * r; }
+                                A_(i, k + 1) -= p * q;
+                                A_(i, k) -= p;
+                            }
+                        }
+                    }
+                }
+            }
+        } while (l < nn - 1);
+    }
+#undef A_
+    return 0;
+}
+
+// Null vector of (h - theta I) by two steps of inverse iteration with partial-pivot
+// Gaussian elimination.  h: n x n (row stride ld, preserved), work: n*n + n doubles.
+SE_HD inline void eigenvector(const double* h, int n, int ld, double theta, double* y, double* work) {
+    double* m = work;  // n x n
+    double* b = work + n * n;
+    int piv[64];
+    double scale = 0.0;
+    for (int i = 0; i < n; ++i)
+        for (int j = 0; j < n; ++j) {
+            m[i * n + j] = h[i * ld + j] - (i == j ? theta : 0.0);
+            scale = fmax(scale, fabs(h[i * ld + j]));
+        }
+    const double tiny = 2.3e-16 * (scale > 0.0 ? scale : 1.0);
+    // LU with partial pivoting, in place
+    for (int c = 0; c < n; ++c) {
+        int pr = c;
+        for (int i = c + 1; i < n; ++i)
+            if (fabs(m[i * n + c]) > fabs(m[pr * n + c])) pr = i;
+        piv[c] = pr;
+        if (pr != c)
+            for (int j = 0; j < n; ++j) { double t = m[c * n + j]; m[c * n + j] = m[pr * n + j]; m[pr * n + j] = t; }
+        if (fabs(m[c * n + c]) < tiny) m[c * n + c] = tiny;  // singular by construction
+        for (int i = c + 1; i < n; ++i) {
+            const double f = m[i * n + c] / m[c * n + c];
+            m[i * n + c] = f;
+            for (int j = c + 1; j < n; ++j) m[i * n + j] -= f * m[c * n + j];
+        }
+    }
+    for (int i = 0; i < n; ++i) y[i] = 1.0;
+    for (int it = 0; it < 3; ++it) {
+        for (int i = 0; i < n; ++i) b[i] = y[i];
+        for (int c = 0; c < n; ++c) {
+            if (piv[c] != c) { double t = b[c]; b[c] = b[piv[c]]; b[piv[c]] = t; }
+            for (int i = c + 1; i < n; ++i) b[i] -= m[i * n + c] * b[c];
+        }
+        for (int i = n - 1; i >= 0; --i) {
+            double s = b[i];
+            for (int j = i + 1; j < n; ++j) s -= m[i * n + j] * y[j];
+            y[i] = s / m[i * n + i];
+        }
+        double nrm = 0.0;
+        for (int i = 0; i < n; ++i) nrm = fmax(nrm, fabs(y[i]));
+        if (nrm > 0.0)
+            for (int i = 0; i < n; ++i) y[i] /= nrm;
+    }
+}
+
+}  // namespace small_eig

@@ -395,6 +395,85 @@ class Engine:
         return out
 
 
+    # -- MSM estimation ---------------------------------------------------------
+    def transition_matrix(self, counts: DeviceArray, *, mode: int = 0, alpha: float = 1e-3,
+                          epsilon: float = 1e-12) -> dict:
+        """counts [k,k] (int64 or float64) -> dict of device arrays (see msm_transition_matrix)."""
+        k = counts.shape[0]
+        if counts.dtype not in (np.dtype(np.int64), np.dtype(np.float64)):
+            raise TypeError("counts must be int64 or float64")
+        T = self.empty((k, k), np.float64)
+        rowsum = self.empty((k,), np.float64)
+        out = {"T": T, "rowsum": rowsum}
+        if mode == 0:
+            dm = self.empty((1,), np.float64)
+            check(lib.msm_transition_matrix(self.handle, counts.ptr, int(counts.dtype == np.float64), k, 0, 0.0, 0.0,
+                                            T.ptr, None, None, None, rowsum.ptr, dm.ptr), self.handle)
+            out["diag_mass"] = dm
+        else:
+            active, inv = self.empty((k,), np.int32), self.empty((k,), np.int32)
+            na = self.empty((1,), np.int32)
+            check(lib.msm_transition_matrix(self.handle, counts.ptr, int(counts.dtype == np.float64), k, 1,
+                                            float(alpha), float(epsilon), T.ptr, active.ptr, inv.ptr, na.ptr,
+                                            rowsum.ptr, None), self.handle)
+            out.update(active=active, inv_map=inv, n_active=na)
+        return out
+
+    def embed_full(self, T_active: DeviceArray, inv_map: DeviceArray, pi_active: DeviceArray | None = None):
+        k = T_active.shape[0]
+        T_full = self.empty((k, k), np.float64)
+        pi_full = self.empty((k,), np.float64)
+        check(lib.msm_embed_full(self.handle, T_active.ptr, pi_active.ptr if pi_active is not None else None,
+                                 inv_map.ptr, k, T_full.ptr, pi_full.ptr), self.handle)
+        return T_full, pi_full
+
+    def spectrum(self, T: DeviceArray, *, n: DeviceArray | None = None, n_its: int = 0, lags=None,
+                 p: int | None = None, want_pi: bool = True, tol: float = 1e-9, n_iter: int = 60,
+                 max_launches: int = 40, seed: int = 0, allow_unconverged: bool = False) -> dict:
+        """Leading Ritz values / stationary distribution / implied timescales of one matrix
+        [k,k] or a batch [B,k,k] of packed row-stochastic matrices (orders in `n`, int32 [B])."""
+        batched = len(T.shape) == 3
+        B = T.shape[0] if batched else 1
+        k = T.shape[-1]
+        if p is None:
+            p = min(32, max(n_its + 1 + 6, 8))
+        p = int(min(p, 32, k))
+        ws_bytes = int(lib.msm_spectrum_workspace_bytes(k, p, B))
+        ws = self.empty((ws_bytes,), np.uint8)
+        ritz = self.empty((B, 128), np.float64)
+        pi = self.empty((B, k), np.float64) if want_pi else None
+        change = self.empty((B,), np.float64)
+        status = self.empty((B,), np.int32)
+        its_eig = self.empty((B, max(n_its, 1)), np.float64)
+        its_ts = self.empty((B, max(n_its, 1)), np.float64)
+        lag_d = self.to_device(np.asarray(lags if lags is not None else np.ones(B), np.float64).reshape(B))
+        launches = 0
+        for launch in range(max_launches):
+            check(lib.msm_spectrum(self.handle, T.ptr, k * k, k, n.ptr if n is not None else None, k, B, p,
+                                   int(n_iter), int(launch == 0), int(seed), max(n_its + 1, 1), ws.ptr, ritz.ptr,
+                                   pi.ptr if pi is not None else None, k, change.ptr, status.ptr, int(n_its),
+                                   lag_d.ptr, its_eig.ptr, its_ts.ptr), self.handle)
+            launches += 1
+            worst = float(np.max(change.to_host()))
+            if worst <= tol:
+                break
+        else:
+            if not allow_unconverged:
+                raise _lib.MsmError(
+                    f"msm_spectrum: residual {worst:.3e} > {tol:.1e} after {launches * n_iter} iterations "
+                    "(leading eigenvalues too clustered for subspace iteration)")
+        st = status.to_host()
+        if np.any(st != 0):
+            raise _lib.MsmError(f"msm_spectrum: hqr did not converge (status {st.tolist()})")
+        r = ritz.to_host()
+        out = {"ritz": r[:, :32] + 1j * r[:, 32:64], "p": p, "launches": launches,
+               "residual": change.to_host(), "pi": pi}
+        if n_its:
+            out["its_eig"] = its_eig.to_host()
+            out["its_ts"] = its_ts.to_host()
+        return out
+
+
 _ENGINES: dict[int, Engine] = {}
 
 

@@ -41,3 +41,18 @@ def markov_labels(n: int, k: int, seed: int, stay: float = 0.9) -> np.ndarray:
     inc = np.where(jump, step, 0)
     inc[0] = rng.integers(0, k)
     return (np.cumsum(inc) % k).astype(np.int32)
+
+
+def metastable_labels(n: int, k: int, n_macro: int, seed: int, p_leave: float = 0.01) -> np.ndarray:
+    """MSM-like trajectory: `n_macro` metastable basins of k/n_macro microstates each, fast
+    mixing inside a basin, rare hops to a neighbouring basin (so the spectrum has n_macro-1
+    slow processes and a gap below them)."""
+    rng = np.random.default_rng(seed)
+    per = k // n_macro
+    hop = rng.random(n) < p_leave
+    step = np.where(rng.random(n) < 0.5, -1, 1)
+    macro = np.cumsum(np.where(hop, step, 0))
+    macro = np.abs(((macro + n_macro - 1) % (2 * n_macro - 2)) - (n_macro - 1)) if n_macro > 1 else macro * 0
+    macro = np.clip(macro, 0, n_macro - 1)
+    micro = rng.integers(0, per, size=n)
+    return (macro * per + micro).astype(np.int32)

@@ -1,0 +1,148 @@
+"""HIP transition matrix / stationary distribution / spectrum / implied timescales vs the
+oracle (numpy restatement of the reference's estimators; tolerances per north_star: 1e-5
+relative on timescales, held much tighter here)."""
+
+from __future__ import annotations
+
+import numpy as np
+import pytest
+
+from oracle import cport, npport
+from tests import _gen
+
+pytestmark = pytest.mark.gpu
+
+
+def _metastable_counts(k, n, lag, seed, n_macro=5):
+    lab = _gen.metastable_labels(n, k, n_macro, seed=seed)
+    c, _ = cport.count_transitions(lab, k, lag)
+    return c, lab
+
+
+def test_normalise_counts_mode0(engine, golden):
+    g = golden("counts.npz")
+    C = g["plain_counts"].astype(np.int64)
+    out = engine.transition_matrix(engine.to_device(C), mode=0)
+    np.testing.assert_array_equal(out["T"].to_host(), g["normalised_plain"])
+    # zero rows stay zero; diag mass = trace/k
+    C2 = C.copy()
+    C2[3, :] = 0
+    out2 = engine.transition_matrix(engine.to_device(C2), mode=0)
+    T2 = out2["T"].to_host()
+    np.testing.assert_array_equal(T2, npport.normalise_counts(C2))
+    assert np.all(T2[3] == 0)
+    np.testing.assert_allclose(out2["diag_mass"].to_host()[0], np.trace(T2) / 7, rtol=1e-15)
+    # float64 (weighted) counts
+    Cw = g["weighted_counts"]
+    # non-integer row sums depend on the summation order at the last bit
+    np.testing.assert_allclose(engine.transition_matrix(engine.to_device(Cw), mode=0)["T"].to_host(),
+                               npport.normalise_counts(Cw), rtol=1e-15)
+
+
+def test_connected_mode1_matches_ml_msm(engine):
+    k = 40
+    C, _ = _metastable_counts(k, 30_000, 5, seed=3, n_macro=4)
+    C[:, 7] = 0
+    C[7, :] = 0          # disconnected state -> inactive
+    C[:, 21] = 0
+    C[21, :] = 0
+    out = engine.transition_matrix(engine.to_device(C), mode=1)
+    ka = int(out["n_active"].to_host()[0])
+    ref = npport.ml_msm(C)
+    assert ka == ref["active"].size == k - 2
+    np.testing.assert_array_equal(out["active"].to_host()[:ka], ref["active"])
+    Ta = out["T"].to_host()[:ka, :ka]
+    Ca, _ = npport.ensure_connected_counts(C)
+    np.testing.assert_allclose(Ta, Ca / Ca.sum(axis=1, keepdims=True), rtol=1e-14)
+    spec = engine.spectrum(out["T"], n=out["n_active"], n_its=3, lags=[5.0])
+    pi = spec["pi"].to_host()[0, :ka]
+    np.testing.assert_allclose(pi, ref["stationary_distribution"][ref["active"]], rtol=1e-8, atol=1e-12)
+    T_full, pi_full = engine.embed_full(out["T"], out["inv_map"], spec["pi"])
+    np.testing.assert_allclose(T_full.to_host(), ref["transition_matrix"], rtol=1e-13, atol=1e-15)
+    np.testing.assert_allclose(pi_full.to_host(), ref["stationary_distribution"], rtol=1e-8, atol=1e-12)
+    assert pi_full.to_host()[7] == 0 and T_full.to_host()[7, 7] == 1.0
+
+
+def test_two_state_chain_analytic(engine):
+    """tests/unit/markov_state_model/test_two_state_msm.py:6-22: t2 = -1/ln(0.8)."""
+    T = np.array([[0.9, 0.1], [0.1, 0.9]])
+    spec = engine.spectrum(engine.to_device(T), n_its=1, lags=[1.0])
+    np.testing.assert_allclose(spec["its_eig"][0], [0.8], rtol=1e-12)
+    np.testing.assert_allclose(spec["its_ts"][0], [-1.0 / np.log(0.8)], rtol=1e-12)
+    np.testing.assert_allclose(spec["pi"].to_host()[0], [0.5, 0.5], rtol=1e-12)
+
+
+@pytest.mark.parametrize("k,n,lag,n_its", [(20, 50_000, 1, 3), (100, 200_000, 10, 5), (200, 300_000, 5, 4),
+                                            (500, 1_000_000, 10, 6)])
+def test_its_vs_oracle(engine, k, n, lag, n_its):
+    C, _ = _metastable_counts(k, n, lag, seed=k)
+    out = engine.transition_matrix(engine.to_device(C), mode=1)
+    spec = engine.spectrum(out["T"], n=out["n_active"], n_its=n_its, lags=[float(lag)])
+    ev_ref, ts_ref = npport.its_from_counts(C, lag, n_its)
+    # north_star: implied timescales within 1e-5 relative
+    np.testing.assert_allclose(spec["its_eig"][0], ev_ref, rtol=1e-8)
+    np.testing.assert_allclose(spec["its_ts"][0], ts_ref, rtol=1e-6)
+    ka = int(out["n_active"].to_host()[0])
+    Ta = out["T"].to_host()[:ka, :ka]
+    pi = spec["pi"].to_host()[0, :ka]
+    assert pi.min() > 0
+    np.testing.assert_allclose(pi @ Ta, pi, atol=1e-12)
+    np.testing.assert_allclose(pi.sum(), 1.0, rtol=1e-13)
+
+
+def test_spectrum_matches_numpy_eigvals_including_complex(engine):
+    """A non-reversible (cyclic-drift) chain has complex leading eigenvalues."""
+    k = 30
+    rng = np.random.default_rng(5)
+    T = np.full((k, k), 1e-3)
+    for i in range(k):
+        T[i, i] += 0.5
+        T[i, (i + 1) % k] += 0.45     # strong drift
+        T[i, (i - 1) % k] += 0.02
+    T += 0.01 * rng.random((k, k))
+    T /= T.sum(axis=1, keepdims=True)
+    spec = engine.spectrum(engine.to_device(T), p=12, n_its=0, tol=1e-11)
+    ref = np.linalg.eigvals(T)
+    ref = ref[np.argsort(-np.abs(ref))]
+    got = spec["ritz"][0][:5]
+    assert np.abs(ref[1].imag) > 1e-3
+    # complex pairs are monitored by value change, not residual: hold them to the
+    # north_star tolerance (1e-5 relative) with a decade to spare
+    np.testing.assert_allclose(np.abs(got), np.abs(ref[:5]), rtol=1e-6)
+    np.testing.assert_allclose(np.sort(got[:5].real), np.sort(ref[:5].real), atol=1e-6)
+
+
+def test_lagscan_batch(engine):
+    """C4-like: k=200, 20 lags in one batched solve (ITS scan, _its.py:272-357)."""
+    k, n = 200, 200_000
+    lab = _gen.metastable_labels(n, k, 5, seed=9)
+    lags = [1, 2, 3, 5, 8, 10, 15, 20, 30, 50]
+    ld = engine.to_device(lab)
+    counts, _ = engine.count_transitions_lagscan(ld, k, lags)
+    Ts, ns = [], []
+    Tb = engine.empty((len(lags), k, k), np.float64)
+    nb = engine.empty((len(lags),), np.int32)
+    for i in range(len(lags)):
+        out = engine.transition_matrix(counts.view((k, k), offset_elems=i * k * k), mode=1)
+        Tb.view((k, k), offset_elems=i * k * k).copy_from_host(out["T"].to_host())
+        nb.view((1,), offset_elems=i).copy_from_host(out["n_active"].to_host())
+    spec = engine.spectrum(Tb, n=nb, n_its=3, lags=[float(v) for v in lags])
+    ch = counts.to_host()
+    for i, lag in enumerate(lags):
+        ev_ref, ts_ref = npport.its_from_counts(ch[i], lag, 3)
+        np.testing.assert_allclose(spec["its_ts"][i], ts_ref, rtol=1e-6)
+
+
+def test_clustered_spectrum_is_reported_not_guessed(engine):
+    """Diffusion on a ring packs dozens of eigenvalues within 1e-3 of 1: subspace iteration
+    cannot resolve them in its budget and must say so instead of returning stale Ritz values."""
+    from pmarlo_amd._lib import MsmError
+
+    k = 300
+    lab = _gen.markov_labels(400_000, k, seed=1, stay=0.97)
+    C, _ = cport.count_transitions(lab, k, 1)
+    out = engine.transition_matrix(engine.to_device(C), mode=1)
+    with pytest.raises(MsmError, match="residual"):
+        engine.spectrum(out["T"], n=out["n_active"], n_its=4, lags=[1.0], max_launches=3)
+    loose = engine.spectrum(out["T"], n=out["n_active"], n_its=4, lags=[1.0], max_launches=3, allow_unconverged=True)
+    assert loose["residual"][0] > 1e-9
