@@ -82,6 +82,33 @@ msm_status msm_graph_launch(msm_ctx* ctx, msm_graph* g);
 void msm_graph_destroy(msm_graph* g);
 
 /* ------------------------------------------------------------------ */
+/* featurizers                                                          */
+/* ------------------------------------------------------------------ */
+
+/* Per-frame geometry on d_xyz float32 [n, A, 3] (nm), written as float32 columns
+ * [col_off, col_off + width) of d_out [n, ld].  fp32 arithmetic in the operation
+ * order of the reference's in-repo extractor (S/features/deeptica/
+ * ts_feature_extractor.py:423-500, use_pbc = False), which is also what stands in
+ * for mdtraj.compute_distances / compute_dihedrals behind featurize_trajectory
+ * (S/features/featurize.py:41-62), PhiPsiFeature / DistanceFeature / AngleFeature /
+ * DihedralFeature (S/features/builtins.py:42-86, 281-395) and
+ * FeaturesMixin._compute_phi_psi_features (S/markov_state_model/_features.py:131-142).
+ *   distances: d_pairs int32 [P, 2]      d = sqrt(max(|x_j - x_i|^2, 1e-12))
+ *   angles   : d_triplets int32 [T, 3]   acos(clamp(v1.v2 / (|v1||v2|), -1, 1)), vertex = middle atom
+ *   dihedrals: d_quads int32 [Q, 4]      atan2 form, wrapped to (-pi, pi] (builtins.py:11-14)
+ *       mode 0: Q columns of radians
+ *       mode 1: 2Q columns [cos_0, sin_0, cos_1, sin_1, ...]  (trig_expand_periodic,
+ *               S/api/features.py:138-180)
+ *       mode 2: 2Q columns [cos_0..cos_{Q-1} | sin_0..sin_{Q-1}] (_features.py:131-142) */
+msm_status msm_featurize_distances(msm_ctx* ctx, const float* d_xyz, int64_t n, int A,
+                                   const int32_t* d_pairs, int P, float* d_out, int64_t ld, int col_off);
+msm_status msm_featurize_angles(msm_ctx* ctx, const float* d_xyz, int64_t n, int A,
+                                const int32_t* d_triplets, int Tn, float* d_out, int64_t ld, int col_off);
+msm_status msm_featurize_dihedrals(msm_ctx* ctx, const float* d_xyz, int64_t n, int A,
+                                   const int32_t* d_quads, int Q, int mode, float* d_out, int64_t ld,
+                                   int col_off);
+
+/* ------------------------------------------------------------------ */
 /* lag-tau transition counts                                            */
 /* ------------------------------------------------------------------ */
 

@@ -51,6 +51,9 @@ _PROTOTYPES: dict[str, tuple] = {
     "msm_graph_end": (_i32, [_vp, _pp]),
     "msm_graph_launch": (_i32, [_vp, _vp]),
     "msm_graph_destroy": (None, [_vp]),
+    "msm_featurize_distances": (_i32, [_vp, _vp, _i64, _i32, _vp, _i32, _vp, _i64, _i32]),
+    "msm_featurize_angles": (_i32, [_vp, _vp, _i64, _i32, _vp, _i32, _vp, _i64, _i32]),
+    "msm_featurize_dihedrals": (_i32, [_vp, _vp, _i64, _i32, _vp, _i32, _i32, _vp, _i64, _i32]),
     "msm_count_transitions": (_i32, [_vp, _vp, _i64, _vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp]),
     "msm_count_transitions_weighted": (
         _i32, [_vp, _vp, _vp, _i64, _vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp]),

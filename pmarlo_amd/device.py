@@ -196,6 +196,39 @@ class Engine:
     def graph_destroy(self, g) -> None:
         lib.msm_graph_destroy(g)
 
+    # -- featurizers -----------------------------------------------------------
+    def featurize(self, xyz: DeviceArray, *, pairs=None, triplets=None, quads=None, dihedral_mode: int = 0,
+                  out: DeviceArray | None = None) -> DeviceArray:
+        """xyz float32 [n, A, 3] -> float32 [n, F]: distance columns, then angle columns, then
+        dihedral columns (mode 0 radians, 1 interleaved cos/sin, 2 cos block | sin block)."""
+        if xyz.dtype != np.float32 or len(xyz.shape) != 3 or xyz.shape[2] != 3:
+            raise ValueError("xyz must be float32 with shape (n_frames, n_atoms, 3)")
+        n, A, _ = xyz.shape
+
+        def _idx(arr, width):
+            if arr is None:
+                return None, 0
+            a = np.ascontiguousarray(arr, np.int32).reshape(-1, width)
+            if a.size and (a.min() < 0 or a.max() >= A):
+                raise ValueError(f"atom index out of range [0, {A})")
+            return (self.to_device(a) if a.size else None), a.shape[0]
+
+        dp, P = _idx(pairs, 2)
+        dt, Tn = _idx(triplets, 3)
+        dq, Q = _idx(quads, 4)
+        width = P + Tn + (Q if dihedral_mode == 0 else 2 * Q)
+        out = out if out is not None else self.empty((n, width), np.float32)
+        ld = out.shape[1]
+        if P:
+            check(lib.msm_featurize_distances(self.handle, xyz.ptr, n, A, dp.ptr, P, out.ptr, ld, 0), self.handle)
+        if Tn:
+            check(lib.msm_featurize_angles(self.handle, xyz.ptr, n, A, dt.ptr, Tn, out.ptr, ld, P), self.handle)
+        if Q:
+            check(lib.msm_featurize_dihedrals(self.handle, xyz.ptr, n, A, dq.ptr, Q, int(dihedral_mode), out.ptr, ld,
+                                              P + Tn), self.handle)
+        self.sync()  # index tables are freed on return
+        return out
+
     # -- transition counts ----------------------------------------------------
     @staticmethod
     def _seg_ptrs(starts: np.ndarray, stops: np.ndarray):

@@ -1,0 +1,66 @@
+"""HIP featurizer kernels vs the golden outputs of the reference's torch extractor and
+the numpy restatement."""
+
+from __future__ import annotations
+
+import numpy as np
+import pytest
+
+from oracle import npport
+
+pytestmark = pytest.mark.gpu
+
+
+def test_chignolin_ca_distances_golden(engine, golden):
+    g = golden("featurizer.npz")
+    out = engine.featurize(engine.to_device(g["chig_xyz"]), pairs=g["chig_pairs"]).to_host()
+    assert out.shape == (36, 45) and out.dtype == np.float32
+    np.testing.assert_allclose(out, g["chig_dist"], rtol=2e-6)
+
+
+def test_alanine_phi_psi_and_angles_golden(engine, golden):
+    g = golden("featurizer.npz")
+    xyz = engine.to_device(g["ala_xyz"])
+    out = engine.featurize(xyz, triplets=g["ala_triplets"], quads=g["ala_quads"]).to_host()
+    np.testing.assert_allclose(out[:, :3], g["ala_angles"], atol=2e-5)
+    np.testing.assert_allclose(out[:, 3:], g["ala_dihedrals"], atol=2e-5)
+    # layouts: interleaved (api/features.py trig_expand) and block (_features.py phi/psi)
+    inter = engine.featurize(xyz, quads=g["ala_quads"], dihedral_mode=1).to_host()
+    block = engine.featurize(xyz, quads=g["ala_quads"], dihedral_mode=2).to_host()
+    phi_psi = g["ala_dihedrals"].astype(np.float64)
+    want_inter, mapping = npport.trig_expand_periodic(phi_psi, np.array([True, True]))
+    np.testing.assert_array_equal(mapping, [0, 0, 1, 1])
+    np.testing.assert_allclose(inter, want_inter, atol=3e-5)
+    np.testing.assert_allclose(block, np.hstack([np.cos(phi_psi), np.sin(phi_psi)]), atol=3e-5)
+
+
+def test_unit_cube_known_answer(engine, golden):
+    """tests/features/deeptica/test_ts_feature_extractor.py:44-74."""
+    g = golden("featurizer.npz")
+    out = engine.featurize(engine.to_device(g["cube_xyz"]), pairs=[[0, 1]], triplets=[[0, 1, 2]],
+                           quads=[[0, 1, 2, 3]]).to_host()
+    np.testing.assert_allclose(out[0], [1.0, np.pi / 2, np.pi / 2], atol=1e-6)
+    np.testing.assert_allclose(out[0], g["cube_feats"], atol=1e-6)
+
+
+def test_large_random_vs_numpy_and_degenerate(engine):
+    rng = np.random.default_rng(0)
+    n, A = 200_000, 22
+    xyz = rng.normal(size=(n, A, 3)).astype(np.float32)
+    xyz[5, 3] = xyz[5, 2]                 # zero-length bond -> clamped, no NaN
+    pairs = [(i, j) for i in range(6) for j in range(i + 1, 6)]
+    quads = [[4, 6, 8, 14], [6, 8, 14, 16], [2, 3, 4, 5]]
+    out = engine.featurize(engine.to_device(xyz), pairs=pairs, quads=quads).to_host()
+    assert np.isfinite(out).all()
+    np.testing.assert_allclose(out[:, :15], npport.distances(xyz, pairs), rtol=3e-6, atol=1e-6)
+    ref = npport.dihedrals(xyz, quads)
+    diff = np.abs(out[:, 15:] - ref)
+    diff = np.minimum(diff, 2 * np.pi - diff)     # +-pi branch
+    assert np.percentile(diff, 99.9) < 1e-4 and diff.max() < 5e-2
+    assert out[:, 15:].max() <= np.float32(np.pi) and out[:, 15:].min() > -np.float32(np.pi)
+
+
+def test_bad_indices_raise(engine):
+    xyz = engine.to_device(np.zeros((2, 4, 3), np.float32))
+    with pytest.raises(ValueError):
+        engine.featurize(xyz, pairs=[[0, 4]])
