@@ -1,0 +1,85 @@
+"""Built-in featurizers on the GPU: mirror of pmarlo.features.builtins
+(S/features/builtins.py:42-86 PhiPsiFeature, :281-395 Distance/Angle/DihedralFeature).
+
+The objects keep the reference's stateful protocol (``labels`` / periodic flags set as a
+side effect of ``compute``), and ``astype(float)`` outputs with NaN -> 0 (:307,346,387)."""
+
+from __future__ import annotations
+
+import numpy as np
+
+from ..device import get_engine
+from .base import register_feature
+
+__all__ = ["PhiPsiFeature", "DistanceFeature", "AngleFeature", "DihedralFeature"]
+
+
+def _device_features(traj, **kw) -> np.ndarray:
+    eng = get_engine()
+    out = eng.featurize(eng.to_device(np.ascontiguousarray(traj.xyz, np.float32)), **kw)
+    return out.to_host()
+
+
+class PhiPsiFeature:
+    name = "phi_psi"
+
+    def __init__(self) -> None:
+        self._periodic: np.ndarray | None = None
+        self.labels: list[str] | None = None
+
+    def compute(self, traj, **kwargs) -> np.ndarray:
+        phi_idx = traj.topology.phi_indices()
+        psi_idx = traj.topology.psi_indices()
+        if len(phi_idx) == 0 and len(psi_idx) == 0:
+            self.labels = []
+            return np.zeros((traj.n_frames, 0), dtype=float)
+        quads = np.vstack([phi_idx, psi_idx])
+        X = _device_features(traj, quads=quads)  # wrapped to (-pi, pi] by the kernel
+        self.labels = ([f"phi:res{int(traj.topology.res_index[q[1]])}" for q in phi_idx]
+                       + [f"psi:res{int(traj.topology.res_index[q[2]])}" for q in psi_idx])
+        self._periodic = np.ones((X.shape[1],), dtype=bool)
+        return X
+
+    def is_periodic(self) -> np.ndarray:
+        return np.empty((0,), dtype=bool) if self._periodic is None else self._periodic
+
+
+class _IndexedFeature:
+    width = 0
+    kw = ""
+    periodic = False
+
+    def __init__(self) -> None:
+        self._periodic: np.ndarray | None = None
+        self.labels: list[str] | None = None
+
+    def compute(self, traj, indices=None, **kwargs) -> np.ndarray:
+        if indices is None or len(indices) != self.width:
+            raise ValueError(f"{self.name} requires {self.width} atom indices")
+        idx = [int(i) for i in indices]
+        if min(idx) < 0 or max(idx) >= traj.n_atoms:
+            raise ValueError(f"{self.name} indices out of range")
+        X = _device_features(traj, **{self.kw: [idx]}).astype(float)
+        X = np.nan_to_num(X, nan=0.0)
+        self._periodic = np.array([self.periodic], dtype=bool)
+        self.labels = [f"{self.name}:" + "-".join(str(i) for i in idx)]
+        return X
+
+    def is_periodic(self) -> np.ndarray:
+        return np.empty((0,), dtype=bool) if self._periodic is None else self._periodic
+
+
+class DistanceFeature(_IndexedFeature):
+    name, width, kw, periodic = "distance", 2, "pairs", False
+
+
+class AngleFeature(_IndexedFeature):
+    name, width, kw, periodic = "angle", 3, "triplets", False
+
+
+class DihedralFeature(_IndexedFeature):
+    name, width, kw, periodic = "dihedral", 4, "quads", True
+
+
+for _cls in (PhiPsiFeature, DistanceFeature, AngleFeature, DihedralFeature):
+    register_feature(_cls())

@@ -1,0 +1,148 @@
+"""PDB reader and the slice of the mdtraj Trajectory/Topology interface that the
+featurizer needs (the input side of the path).
+
+The reference hands ``mdtraj.Trajectory`` objects to its featurizers
+(S/features/featurize.py:17-66, S/io/trajectory.py:136-177).  mdtraj's C readers are
+out of scope; this module gives the same attributes for PDB input: ``xyz`` float32
+(n_frames, n_atoms, 3) in nm, ``n_frames``, ``n_atoms``, ``topology.select("name CA")``,
+and the backbone dihedral index tables of ``mdtraj.compute_phi / compute_psi``."""
+
+from __future__ import annotations
+
+from dataclasses import dataclass, field
+from pathlib import Path
+
+import numpy as np
+
+__all__ = ["Topology", "Trajectory", "load_pdb"]
+
+
+@dataclass
+class Topology:
+    atom_names: list[str]
+    res_names: list[str]
+    res_index: np.ndarray          # per-atom 0-based residue index (in file order)
+    chain_ids: list[str] = field(default_factory=list)
+
+    @property
+    def n_atoms(self) -> int:
+        return len(self.atom_names)
+
+    @property
+    def n_residues(self) -> int:
+        return int(self.res_index.max()) + 1 if len(self.res_index) else 0
+
+    def select(self, query: str) -> np.ndarray:
+        """Supports the selections the path uses: ``name X`` and ``all``."""
+        q = query.strip()
+        if q == "all":
+            return np.arange(self.n_atoms)
+        parts = q.split()
+        if len(parts) == 2 and parts[0] == "name":
+            return np.asarray([i for i, nm in enumerate(self.atom_names) if nm == parts[1]], dtype=int)
+        raise ValueError(f"unsupported selection {query!r} (supported: 'all', 'name <atom>')")
+
+    def _atom(self, res: int, name: str) -> int | None:
+        for i in np.nonzero(self.res_index == res)[0]:
+            if self.atom_names[i] == name:
+                return int(i)
+        return None
+
+    def _same_chain(self, r1: int, r2: int) -> bool:
+        if not self.chain_ids:
+            return True
+        a = np.nonzero(self.res_index == r1)[0]
+        b = np.nonzero(self.res_index == r2)[0]
+        return len(a) > 0 and len(b) > 0 and self.chain_ids[a[0]] == self.chain_ids[b[0]]
+
+    def phi_indices(self) -> np.ndarray:
+        """C(i-1), N(i), CA(i), C(i) for every residue that has them (mdtraj.compute_phi)."""
+        out = []
+        for r in range(1, self.n_residues):
+            if not self._same_chain(r - 1, r):
+                continue
+            quad = [self._atom(r - 1, "C"), self._atom(r, "N"), self._atom(r, "CA"), self._atom(r, "C")]
+            if None not in quad:
+                out.append(quad)
+        return np.asarray(out, dtype=np.int32).reshape(-1, 4)
+
+    def psi_indices(self) -> np.ndarray:
+        """N(i), CA(i), C(i), N(i+1) (mdtraj.compute_psi)."""
+        out = []
+        for r in range(0, self.n_residues - 1):
+            if not self._same_chain(r, r + 1):
+                continue
+            quad = [self._atom(r, "N"), self._atom(r, "CA"), self._atom(r, "C"), self._atom(r + 1, "N")]
+            if None not in quad:
+                out.append(quad)
+        return np.asarray(out, dtype=np.int32).reshape(-1, 4)
+
+
+@dataclass
+class Trajectory:
+    xyz: np.ndarray                # float32 (n_frames, n_atoms, 3), nanometres
+    topology: Topology
+
+    def __post_init__(self):
+        self.xyz = np.ascontiguousarray(self.xyz, dtype=np.float32)
+        if self.xyz.ndim != 3 or self.xyz.shape[2] != 3 or self.xyz.shape[1] != self.topology.n_atoms:
+            raise ValueError(f"xyz shape {self.xyz.shape} does not match topology ({self.topology.n_atoms} atoms)")
+
+    @property
+    def n_frames(self) -> int:
+        return int(self.xyz.shape[0])
+
+    @property
+    def n_atoms(self) -> int:
+        return int(self.xyz.shape[1])
+
+    def __len__(self) -> int:
+        return self.n_frames
+
+    def __getitem__(self, key) -> "Trajectory":
+        xyz = self.xyz[key]
+        if xyz.ndim == 2:
+            xyz = xyz[None]
+        return Trajectory(xyz, self.topology)
+
+
+def load_pdb(path: str | Path) -> Trajectory:
+    """Read ATOM/HETATM records of every MODEL (coordinates in Angstrom -> nm)."""
+    models: list[list[list[float]]] = []
+    cur: list[list[float]] = []
+    names: list[str] = []
+    resn: list[str] = []
+    chains: list[str] = []
+    res_keys: list[tuple] = []
+    first = True
+    with open(path) as fh:
+        for line in fh:
+            rec = line[:6]
+            if rec in ("ATOM  ", "HETATM"):
+                cur.append([float(line[30:38]), float(line[38:46]), float(line[46:54])])
+                if first:
+                    names.append(line[12:16].strip())
+                    resn.append(line[17:20].strip())
+                    chains.append(line[21:22])
+                    res_keys.append((line[21:22], line[22:27]))
+            elif rec == "ENDMDL":
+                if cur:
+                    models.append(cur)
+                cur = []
+                first = False
+    if cur:
+        models.append(cur)
+    if not models:
+        raise ValueError(f"{path}: no ATOM records")
+    n_atoms = len(names)
+    if any(len(m) != n_atoms for m in models):
+        raise ValueError(f"{path}: models differ in atom count")
+    res_index = np.zeros(n_atoms, dtype=int)
+    idx, last = -1, None
+    for i, key in enumerate(res_keys):
+        if key != last:
+            idx += 1
+            last = key
+        res_index[i] = idx
+    xyz = np.asarray(models, dtype=np.float64) / 10.0
+    return Trajectory(xyz.astype(np.float32), Topology(names, resn, res_index, chains))

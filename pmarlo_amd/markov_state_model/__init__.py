@@ -1,0 +1,7 @@
+"""pmarlo.markov_state_model operators on the MI355X engine."""
+from .clustering import ClusteringResult, cluster_microstates  # noqa: F401
+from .estimation import (build_msm, compute_free_energies, count_transitions,  # noqa: F401
+                         ensure_connected_counts, finalize_transition_and_stationary)
+from .its import compute_implied_timescales, safe_timescales  # noqa: F401
+from .reduction import reduce_features, tica_reduce  # noqa: F401
+from .results import ConnectedCountResult, ITSResult, MSMEstimate  # noqa: F401

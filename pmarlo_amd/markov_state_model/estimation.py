@@ -1,0 +1,103 @@
+"""MSM estimation hooks: mirror of EstimationMixin (S/markov_state_model/_estimation.py:
+116-156 _count_transitions_deeptime, :158-188 _finalize_transition_and_stationary,
+:211-220 _compute_free_energies) and ensure_connected_counts (S/utils/msm_utils.py:129-167)."""
+
+from __future__ import annotations
+
+from typing import Sequence
+
+import numpy as np
+
+from ..device import get_engine
+from .results import ConnectedCountResult, MSMEstimate
+
+__all__ = ["count_transitions", "ensure_connected_counts", "finalize_transition_and_stationary", "build_msm",
+           "compute_free_energies"]
+
+NUMERIC_MIN_POSITIVE = 1e-12
+NUMERIC_DIRICHLET_ALPHA = 1e-3
+
+
+def _concat_dtrajs(dtrajs: Sequence[np.ndarray], n_states: int):
+    """Concatenate label arrays; out-of-range labels split segments exactly like the reference's
+    Python loop (:133-145) because the count kernel skips any pair touching an invalid label...
+    a pair may not BRIDGE an invalid frame though, so invalid frames also cut segments."""
+    arrays, segs, off = [], [], 0
+    for d in dtrajs:
+        a = np.asarray(d)
+        if a.size == 0:
+            continue
+        a = a.astype(np.int32, copy=False)
+        valid = (a >= 0) & (a < n_states)
+        if valid.all():
+            segs.append((off, off + a.size))
+        else:
+            edges = np.flatnonzero(np.diff(np.concatenate([[0], valid.view(np.int8), [0]])))
+            for s, e in zip(edges[::2], edges[1::2]):
+                segs.append((off + int(s), off + int(e)))
+        arrays.append(a)
+        off += a.size
+    labels = np.concatenate(arrays) if arrays else np.zeros(0, np.int32)
+    return labels, segs
+
+
+def count_transitions(dtrajs: Sequence[np.ndarray], n_states: int, *, lag: int, count_mode: str = "sliding") -> np.ndarray:
+    """(n, n) float64 sliding-window counts; ``"strided"`` is mapped to sliding as the reference does (:152)."""
+    if count_mode not in ("sliding", "strided"):
+        raise ValueError(f"unsupported count_mode {count_mode!r} on the accelerated path")
+    labels, segs = _concat_dtrajs(dtrajs, n_states)
+    if labels.size == 0 or not segs:
+        return np.zeros((n_states, n_states), dtype=float)
+    eng = get_engine()
+    starts = np.asarray([s for s, _ in segs], np.int64)
+    stops = np.asarray([e for _, e in segs], np.int64)
+    counts, _ = eng.count_transitions(eng.to_device(labels), n_states, int(max(1, lag)), starts=starts, stops=stops)
+    return counts.to_host().astype(float)
+
+
+def ensure_connected_counts(C: np.ndarray, alpha: float = NUMERIC_DIRICHLET_ALPHA,
+                            epsilon: float = NUMERIC_MIN_POSITIVE) -> ConnectedCountResult:
+    C = np.asarray(C)
+    if C.ndim != 2 or C.shape[0] != C.shape[1]:
+        raise ValueError("count matrix must be square")
+    totals = C.sum(axis=1) + C.sum(axis=0)
+    active = np.where(totals > epsilon)[0]
+    if active.size == 0:
+        return ConnectedCountResult(np.empty((0, 0), dtype=float), active)
+    return ConnectedCountResult(C[np.ix_(active, active)].astype(float) + float(alpha), active)
+
+
+def finalize_transition_and_stationary(counts: np.ndarray) -> MSMEstimate:
+    """Regularised active set, row-normalised T (ML-MSM, reversible=False), stationary vector;
+    T_full = I outside the active block, pi_full = 0 there.  All numerics on the device."""
+    C = np.ascontiguousarray(counts, dtype=np.float64)
+    n = C.shape[0]
+    eng = get_engine()
+    out = eng.transition_matrix(eng.to_device(C), mode=1)
+    ka = int(out["n_active"].to_host()[0])
+    cm = np.zeros((n, n))
+    if ka == 0:
+        return MSMEstimate(cm, np.eye(n), np.zeros(n), np.zeros(0, dtype=int))
+    spec = eng.spectrum(out["T"], n=out["n_active"], n_its=0)
+    T_full, pi_full = eng.embed_full(out["T"], out["inv_map"], spec["pi"])
+    active = out["active"].to_host()[:ka].astype(int)
+    cm[np.ix_(active, active)] = C[np.ix_(active, active)] + NUMERIC_DIRICHLET_ALPHA
+    return MSMEstimate(cm, T_full.to_host(), pi_full.to_host(), active)
+
+
+def compute_free_energies(stationary_distribution: np.ndarray, temperature: float = 300.0) -> np.ndarray:
+    kT = 1.380649e-23 * temperature * 6.02214076e23 / 1000.0  # kJ/mol (scipy.constants values)
+    F = -kT * np.log(np.maximum(stationary_distribution, NUMERIC_MIN_POSITIVE))
+    return F - np.min(F)
+
+
+def build_msm(dtrajs: Sequence[np.ndarray], n_states: int, lag_time: int = 20, count_mode: str = "sliding",
+              temperature: float = 300.0) -> MSMEstimate:
+    """build_msm (:50-100) minus the orchestration: counts -> T, pi -> free energies."""
+    lens = [len(d) for d in dtrajs if len(d)]
+    lag = int(max(1, lag_time))
+    if lens and lag > min(lens) - 1 > 0:
+        lag = min(lens) - 1  # _validate_and_cap_lag (:102-114)
+    est = finalize_transition_and_stationary(count_transitions(dtrajs, n_states, lag=lag, count_mode=count_mode))
+    est.free_energies = compute_free_energies(est.stationary_distribution, temperature)
+    return est

@@ -1,0 +1,298 @@
+"""Operator-API shims (pmarlo_amd.features / .analysis / .markov_state_model) on the GPU.
+The cases follow the reference's own tests (cited per test) so the two suites read alike."""
+
+from __future__ import annotations
+
+import json
+
+import numpy as np
+import pytest
+
+from oracle import cport, npport
+from tests import _gen
+from tests.conftest import GOLDEN
+
+pytestmark = pytest.mark.gpu
+
+
+def _make_dataset(train, val=None, test=None):
+    splits = {"train": {"X": np.asarray(train, dtype=np.float64)}}
+    if val is not None:
+        splits["val"] = {"X": np.asarray(val, dtype=np.float64)}
+    if test is not None:
+        splits["test"] = {"X": np.asarray(test, dtype=np.float64)}
+    return {"splits": splits}
+
+
+# ---- pmarlo.analysis (tests/analysis/test_discretize.py) -----------------------------
+def test_prepare_msm_discretization_kmeans_assigns_all_splits(engine):
+    from pmarlo_amd.analysis import prepare_msm_discretization
+
+    train = np.array([[0.0, 0.0], [4.0, 4.0], [0.1, -0.1], [4.2, 3.9]])
+    val = np.array([[0.05, 0.05], [4.1, 4.1]])
+    test = np.array([[0.2, -0.05], [4.05, 4.02]])
+    dataset = _make_dataset(train, val=val, test=test)
+    dataset["splits"]["train"]["segments"] = [{"length": train.shape[0]}]
+    result = prepare_msm_discretization(dataset, n_microstates=2, lag_time=1, random_state=0)
+    assert set(result.assignments) == {"train", "val", "test"}
+    assert result.counts.shape == (2, 2)
+    for name, arr in result.assignments.items():
+        assert arr.shape[0] == dataset["splits"][name]["X"].shape[0] and arr.dtype == np.int32
+    assert result.feature_schema["n_features"] == 2
+    assert result.segment_lengths["train"] == [4] and result.segment_strides["train"] == [1]
+    assert result.counted_pairs["train"] == result.expected_pairs["train"] == 3
+    assert result.fingerprint["expected_pairs"] == 3 and result.fingerprint["counted_pairs"] == 3
+    art = dataset["__artifacts__"]
+    for key in ("feature_stats", "state_assignments", "segment_lengths", "expected_pairs", "counted_pairs",
+                "segment_strides"):
+        assert key in art
+    assert art["state_assignments"]["train"] == {"n_assigned": 4, "total": 4}
+    for mask in result.assignment_masks.values():
+        assert mask.dtype == np.bool_ and mask.all()
+    # the two blobs are separated: frames 0,2 share a state, frames 1,3 the other
+    a = result.assignments["train"]
+    assert a[0] == a[2] != a[1] == a[3]
+    assert result.assignments["val"][0] == a[0] and result.assignments["val"][1] == a[1]
+
+
+def test_prepare_msm_expected_pairs_use_segment_stride_metadata(engine):
+    from pmarlo_amd.analysis import expected_pairs, prepare_msm_discretization
+
+    train = np.array([[0.0, 0.0], [0.1, -0.1], [0.2, 0.05], [0.3, -0.2]])
+    dataset = _make_dataset(train)
+    dataset["splits"]["train"]["segments"] = [{"length": 4, "stride": 2}]
+    dataset["splits"]["train"]["feature_schema"] = {"names": ["feature_0", "feature_1"], "n_features": 2}
+    result = prepare_msm_discretization(dataset, n_microstates=2, lag_time=1, random_state=0)
+    assert result.segment_strides["train"] == [2]
+    assert result.expected_pairs["train"] == expected_pairs([4], 1, [2]) == result.fingerprint["expected_pairs"]
+
+
+def test_weighted_counts_use_starting_frame_weights(engine):
+    from pmarlo_amd.analysis import prepare_msm_discretization
+
+    train = np.array([[0.0, 0.0], [0.05, -0.05], [5.0, 5.0], [5.1, 5.2]])
+    weights = np.array([1.0, 0.5, 2.0, 3.0])
+    result = prepare_msm_discretization(_make_dataset(train), n_microstates=2, lag_time=1,
+                                        frame_weights={"train": weights}, random_state=0)
+    labels = result.assignments["train"]
+    expected = np.zeros_like(result.counts)
+    for idx in range(labels.size - 1):
+        expected[labels[idx], labels[idx + 1]] += weights[idx]
+    assert np.allclose(result.counts, expected)
+    assert result.counted_pairs["train"] == result.expected_pairs["train"] == 3
+
+
+def test_discretize_dataset_golden_parity_with_reference_centres(engine):
+    """Full discretize_dataset result of the REFERENCE (3 splits, 2 segments, weights) reproduced
+    when its fitted centres are supplied: labels bit-exact, counts / T to summation order."""
+    from pmarlo_amd.analysis import prepare_msm_discretization
+
+    g = np.load(GOLDEN / "discretize.npz")
+    meta = json.loads((GOLDEN / "discretize.json").read_text())
+    ds = {"splits": {
+        "train": {"X": g["train"], "segments": [{"length": 250}, {"start": 250, "stop": 600, "stride": 2}]},
+        "val": {"X": g["val"]}, "test": {"X": g["test"]}}}
+    res = prepare_msm_discretization(ds, n_microstates=8, lag_time=2, random_state=3,
+                                     frame_weights={"train": g["weights"]}, centers=g["centers"])
+    for split in ("train", "val", "test"):
+        np.testing.assert_array_equal(res.assignments[split], g[f"a_{split}"])
+    np.testing.assert_allclose(res.fingerprint["scaler"]["mean"], meta["scaler"]["mean"], rtol=1e-13)
+    np.testing.assert_allclose(res.fingerprint["scaler"]["std"], meta["scaler"]["std"], rtol=1e-12)
+    np.testing.assert_allclose(res.counts, g["counts"], rtol=1e-12)
+    np.testing.assert_allclose(res.transition_matrix, g["transition_matrix"], rtol=1e-12)
+    np.testing.assert_allclose(res.diag_mass, float(g["diag_mass"]), rtol=1e-12)
+    np.testing.assert_allclose(res.state_counts, g["state_counts"], rtol=1e-12)
+    assert res.segment_lengths == meta["segment_lengths"] and res.segment_strides == meta["segment_strides"]
+    assert res.counted_pairs == meta["counted_pairs"] and res.expected_pairs == meta["expected_pairs"]
+    fp = {k: v for k, v in res.fingerprint.items() if k != "scaler"}
+    assert fp == meta["fingerprint"]
+    assert sorted(ds["__artifacts__"].keys()) == meta["artifacts_keys"]
+
+
+def test_discretize_validation_errors(engine):
+    from pmarlo_amd.analysis import ValidationError, discretize_dataset
+
+    X = np.random.default_rng(0).normal(size=(50, 3))
+    with pytest.raises(ValueError):
+        discretize_dataset(_make_dataset(X), lag_time=0)
+    bad = X.copy()
+    bad[:, 1] = 1.0
+    with pytest.raises(ValidationError) as ei:
+        discretize_dataset(_make_dataset(bad), n_microstates=3)
+    assert ei.value.code == "cv_zero_std"
+    with pytest.raises(ValueError):
+        discretize_dataset({"splits": {}})
+    with pytest.raises(ValueError):
+        discretize_dataset(_make_dataset(X), n_microstates=3, frame_weights={"train": np.ones(7)})
+
+
+# ---- reduction (tests/unit/.../test_reduction.py:43-60) -------------------------------
+def test_tica_reduce_matches_restated_deeptime(engine):
+    from pmarlo_amd.markov_state_model import tica_reduce
+
+    X = _gen.correlated_series(20_000, 12, seed=21)
+    Y = tica_reduce(X, lag=10, n_components=3)
+    Yo = npport.tica_reduce(X, lag=10, n_components=3)
+    assert Y.shape == (20_000, 3) and Y.dtype == np.float64 and Y.flags.c_contiguous
+    for c in range(3):  # up to column sign, atol 1e-6 as in the reference test
+        s = np.sign(np.dot(Y[:, c], Yo[:, c]))
+        np.testing.assert_allclose(s * Y[:, c], Yo[:, c], atol=1e-6)
+
+
+def test_maybe_apply_tica_drops_lag_frames_per_trajectory(engine):
+    """_features.py:181-231: dims clamped to [2,5], last `lag` frames of each trajectory dropped."""
+    from pmarlo_amd.markov_state_model.reduction import tica_fit_transform_trajectories
+
+    lens = [600, 600, 600]
+    feats = np.vstack([_gen.correlated_series(n, 12, seed=i) for i, n in enumerate(lens)])
+    Y, model = tica_fit_transform_trajectories(feats, lens, n_components_hint=9, lag=5)
+    assert Y.shape == (sum(lens) - 3 * 5, 5)
+    Xs = [feats[600 * i:600 * (i + 1)].astype(np.float64) for i in range(3)]
+    ref = npport.tica_fit(Xs, 5, dim=5)
+    np.testing.assert_allclose(model.eigenvalues.to_host()[:5], ref["eigenvalues"][:5], rtol=1e-8)
+
+
+# ---- clustering (tests/unit/.../test_cluster_micro.py, perf determinism) ----------------
+def test_cluster_microstates_contract(engine):
+    from pmarlo_amd.markov_state_model import ClusteringResult, cluster_microstates
+
+    Y, _ = _gen.gaussian_clusters(5, 800, 10, seed=42)
+    Y = Y[np.random.default_rng(0).permutation(Y.shape[0])]
+    res = cluster_microstates(Y, n_states=5, random_state=7)
+    assert isinstance(res, ClusteringResult) and res.output_shape == (res.n_states,)
+    assert res.labels.shape == (4000,) and res.labels.min() == 0 and res.labels.max() == res.n_states - 1
+    for j in range(res.n_states):  # centres are member means (clustering.py:364-392)
+        np.testing.assert_allclose(res.centers[j], Y[res.labels == j].mean(axis=0), rtol=1e-12)
+    again = cluster_microstates(Y, n_states=5, random_state=7)
+    np.testing.assert_array_equal(res.labels, again.labels)  # determinism under a fixed seed
+    with pytest.raises(TypeError):
+        cluster_microstates(Y, n_states=5, bogus=1)
+    with pytest.raises(ValueError):
+        cluster_microstates(Y[:, 0], n_states=5)
+    empty = cluster_microstates(np.zeros((0, 3)), n_states=4)
+    assert empty.n_states == 0 and empty.labels.size == 0
+
+
+# ---- estimation (test_markov_state_model.py:18-61, test_deeptime_backend.py:95-109) -------
+def test_build_msm_invariants_and_oracle(engine):
+    from pmarlo_amd.markov_state_model import build_msm, count_transitions
+
+    rng = np.random.default_rng(42)
+    T_true = np.array([[0.7, 0.2, 0.1], [0.2, 0.7, 0.1], [0.1, 0.2, 0.7]])
+    traj = np.empty(60_000, dtype=int)
+    traj[0] = 0
+    u = rng.random(traj.size)
+    cdf = np.cumsum(T_true, axis=1)
+    for i in range(1, traj.size):
+        traj[i] = int(np.searchsorted(cdf[traj[i - 1]], u[i]))
+    dtrajs = [traj[:25_000], traj[25_000:]]
+    C = count_transitions(dtrajs, 3, lag=1)
+    want = sum(cport.count_transitions(d, 3, 1)[0] for d in dtrajs)
+    np.testing.assert_array_equal(C, want.astype(float))
+    est = build_msm(dtrajs, 3, lag_time=1)
+    ref = npport.ml_msm(C)
+    np.testing.assert_allclose(est.transition_matrix, ref["transition_matrix"], rtol=1e-13)
+    np.testing.assert_allclose(est.stationary_distribution, ref["stationary_distribution"], rtol=1e-9)
+    np.testing.assert_allclose(est.transition_matrix.sum(axis=1), 1.0, atol=1e-12)
+    np.testing.assert_allclose(est.transition_matrix.T @ est.stationary_distribution, est.stationary_distribution,
+                               atol=1e-12)
+    np.testing.assert_allclose(est.transition_matrix, T_true, atol=2e-2)
+    est2 = build_msm(dtrajs, 3, lag_time=2)  # Chapman-Kolmogorov, atol 2e-2 as in the reference
+    np.testing.assert_allclose(est2.transition_matrix, est.transition_matrix @ est.transition_matrix, atol=2e-2)
+    assert est.free_energies.min() == 0.0
+    # invalid labels split trajectories (no pair bridges them)
+    bad = traj[:1000].copy()
+    bad[500] = -1
+    Cb = count_transitions([bad], 3, lag=3)
+    wb = cport.count_transitions(bad[:500], 3, 3)[0] + cport.count_transitions(bad[501:], 3, 3)[0]
+    np.testing.assert_array_equal(Cb, wb.astype(float))
+
+
+# ---- ITS (test_two_state_msm.py:6-22, test_its_plateau.py:6-40, test_its_math.py) -----------
+def test_implied_timescales_two_state_and_plateau(engine, golden):
+    from pmarlo_amd.markov_state_model import compute_implied_timescales, safe_timescales
+
+    rng = np.random.default_rng(0)
+    n = 200_000
+    flips = rng.random(n) < 0.1
+    traj = (np.cumsum(flips) % 2).astype(int)   # T = [[0.9, 0.1], [0.1, 0.9]] -> lambda2 = 0.8
+    res = compute_implied_timescales([traj], 2, lag_times=[1, 2, 3, 5, 8], n_timescales=1)
+    np.testing.assert_array_equal(res.lag_times, [1, 2, 3, 5, 8])
+    assert res.timescales.shape == (5, 1) and res.timescales_ci.shape == (5, 1, 2)
+    t_true = -1.0 / np.log(0.8)
+    assert abs(res.timescales[0, 0] - t_true) / t_true < 0.10          # reference tolerance: 10 %
+    assert np.all(np.abs(res.timescales[:, 0] - t_true) / t_true < 0.20)  # plateau over lags: 20 %
+    np.testing.assert_allclose(res.rates, 1.0 / res.timescales)
+    for i, lag in enumerate(res.lag_times):  # deterministic definition == oracle, 1e-5 relative (north_star)
+        C, _ = cport.count_transitions(traj.astype(np.int32), 2, int(lag))
+        _, ts_ref = npport.its_from_counts(C, int(lag), 1)
+        np.testing.assert_allclose(res.timescales[i], ts_ref, rtol=1e-8)
+    g = golden("timescales.npz")
+    np.testing.assert_array_equal(safe_timescales(25, g["eig"]), g["ts_lag25"])
+    np.testing.assert_array_equal(safe_timescales(5.0, g["ceig"]), g["cts_lag5"])
+    assert compute_implied_timescales([traj[:3]], 2, lag_times=[5]).lag_times.size == 0
+
+
+# ---- features (registry + featurize_trajectory) ------------------------------------------------
+_PDB = """\
+ATOM      1  N   ALA A   1      -0.677  -1.230  -0.491  1.00  0.00           N
+ATOM      2  CA  ALA A   1      -0.001   0.064  -0.491  1.00  0.00           C
+ATOM      3  C   ALA A   1       1.499  -0.110  -0.491  1.00  0.00           C
+ATOM      4  O   ALA A   1       2.030  -1.227  -0.502  1.00  0.00           O
+ATOM      5  N   GLY A   2       2.250   1.000  -0.400  1.00  0.00           N
+ATOM      6  CA  GLY A   2       3.700   0.950  -0.300  1.00  0.00           C
+ATOM      7  C   GLY A   2       4.300   2.300   0.100  1.00  0.00           C
+ATOM      8  O   GLY A   2       3.600   3.300   0.200  1.00  0.00           O
+ATOM      9  N   SER A   3       5.600   2.350   0.350  1.00  0.00           N
+ATOM     10  CA  SER A   3       6.300   3.600   0.700  1.00  0.00           C
+ATOM     11  C   SER A   3       7.800   3.400   0.900  1.00  0.00           C
+ATOM     12  O   SER A   3       8.300   2.300   0.800  1.00  0.00           O
+END
+"""
+
+
+def test_feature_registry_and_featurize_trajectory(engine, tmp_path):
+    from pmarlo_amd.features import featurize_trajectory, get_feature, parse_feature_spec, register_feature
+    from pmarlo_amd.io import Trajectory, load_pdb
+
+    p = tmp_path / "tri.pdb"
+    p.write_text(_PDB)
+    base = load_pdb(p)
+    assert base.n_atoms == 12 and base.topology.n_residues == 3
+    np.testing.assert_array_equal(base.topology.phi_indices(), [[2, 4, 5, 6], [6, 8, 9, 10]])
+    np.testing.assert_array_equal(base.topology.psi_indices(), [[0, 1, 2, 4], [4, 5, 6, 8]])
+    rng = np.random.default_rng(1234)
+    xyz = np.tile(base.xyz, (500, 1, 1)) + rng.normal(0, 0.02, size=(500, 12, 3)).astype(np.float32)
+    traj = Trajectory(xyz, base.topology)
+    X = featurize_trajectory(traj, "phi_psi")
+    quads = np.vstack([base.topology.phi_indices(), base.topology.psi_indices()])
+    np.testing.assert_allclose(X, npport.dihedrals(traj.xyz, quads), atol=3e-5)
+    D = featurize_trajectory(traj, "ca_distances")
+    np.testing.assert_allclose(D, npport.distances(traj.xyz, [[1, 5], [1, 9], [5, 9]]), rtol=3e-6)
+    with pytest.raises(ValueError):
+        featurize_trajectory(traj, "nope")
+    phi_psi = get_feature("phi_psi")
+    Xr = phi_psi.compute(traj)
+    np.testing.assert_array_equal(Xr, X)
+    assert phi_psi.is_periodic().tolist() == [True] * 4 and phi_psi.labels[0].startswith("phi:res")
+    name, kw = parse_feature_spec("distance([1, 5])")
+    d = get_feature(name).compute(traj, **kw)
+    np.testing.assert_allclose(d[:, 0], D[:, 0].astype(float), rtol=0, atol=0)
+    assert get_feature("distance").is_periodic().tolist() == [False]
+    with pytest.raises(ValueError):
+        get_feature("distance").compute(traj, indices=[1, 99])
+    with pytest.raises(KeyError):
+        get_feature("unknown_feature")
+
+    class Mine:  # last registration wins (base.py:30-33)
+        name = "phi_psi"
+
+        def compute(self, traj, **kw):
+            return np.zeros((traj.n_frames, 1))
+
+        def is_periodic(self):
+            return np.zeros(1, bool)
+
+    register_feature(Mine())
+    assert get_feature("PHI_PSI").compute(traj).shape == (500, 1)
+    register_feature(phi_psi)
