@@ -182,6 +182,15 @@ msm_status msm_moments_finalize(msm_ctx* ctx, const double* d_sums, const double
 msm_status msm_column_moments(msm_ctx* ctx, const void* d_x, msm_dtype dtype, int64_t n, int F,
                               int64_t ld, int ddof, double* d_mean, double* d_std, double* d_count);
 
+/* mean / divisor / reciprocal divisor of reduction._preprocess (reduction.py:13-40) from the
+ * raw sums, on the device (no host round trip between the moments and covariance passes):
+ * mean = shift + S1/cnt; sigma = sqrt((S2 - S1^2/cnt)/n_rows) -- NaNs imputed with the
+ * column mean count in n_rows (the total row count over all shards) -- and sigma < 10 eps
+ * -> 1 (sklearn's zero-scale rule); with_std == 0 gives sigma = 1 (scale=False). */
+msm_status msm_standardise_params(msm_ctx* ctx, const double* d_sums, const double* d_shift, int F,
+                                  double n_rows, int with_std, double* d_mean, double* d_scale,
+                                  double* d_inv_scale);
+
 /* Raw time-lagged moments on the fp64 matrix cores.  Replaces the covariance
  * accumulation inside deeptime TICA.fit as called by reduction.tica_reduce
  * (S/markov_state_model/reduction.py:103-109) and FeaturesMixin._maybe_apply_tica

@@ -397,6 +397,222 @@ msm_status dispatch_accum(msm_ctx* ctx, const T* x, int64_t n, int d, int64_t ld
     return msm_fail(ctx, MSM_ERR_UNSUPPORTED, "k-means fit: d=%d > 64 not supported yet", d);
 }
 
+// ---------------------------------------------------------------------------
+// Matrix-core path: the distance table is the GEMM  dot[c][t] = sum_f C[c][f] z[t][f].
+// One v_mfma_f64_16x16x4_f64 covers 16 centres x 16 frames x 4 features:
+//   A (centres): lane l holds C[c0 + (l & 15)][4s + (l >> 4)]      (from the LDS tile)
+//   B (frames) : lane l holds z[t0 + (l & 15)][4s + (l >> 4)]      (registers, loaded once)
+//   D          : lane l, reg r = dot[c0 + (l >> 4) + 4r][t0 + (l & 15)]
+// A wave keeps NF groups of 16 frames resident and walks all centre tiles, so each
+// A fragment feeds NF MFMAs.  With the accumulator starting at +0.0 and the k-steps
+// in ascending feature order the hardware's chain D = fma(a3,b3, fma(a2,b2, fma(a1,b1,
+// fma(a0,b0,C)))) is exactly the pinned ascending-feature FMA chain of the oracle
+// (padding features multiply 0 by 0), so labels stay bit-reproducible.  The VALU
+// only does dist = fma(-2, dot, |c|^2) and the running arg-min; the 4 lanes that share a
+// frame merge their candidates (smaller distance, then smaller index) at the end.
+// ---------------------------------------------------------------------------
+typedef double v4f64 __attribute__((ext_vector_type(4)));
+
+template <typename T, int KS, int NF, bool ACCUM>
+__global__ __launch_bounds__(kThreads, 2) void kmeans_mfma_kernel(
+    const T* __restrict__ x, int64_t n, int d, int64_t ld, const double* __restrict__ centers, int k,
+    const double* __restrict__ mean, const double* __restrict__ stdv, int tile_k /* multiple of 16 */,
+    int32_t* __restrict__ labels, double* __restrict__ mindist, const FitState* __restrict__ st,
+    unsigned long long* __restrict__ sums, unsigned long long* __restrict__ counts, int lds_acc) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    constexpr int DP = 4 * KS;
+    if constexpr (ACCUM) {
+        if (st->done != 0.0) return;
+    }
+    // centre tile, k-step major so that a wave's A read is one contiguous 512-byte run:
+    // cs[(j / 16) * KS * 64 + s * 64 + g * 16 + (j % 16)] = C[k0 + j][4s + g]
+    double* cs = reinterpret_cast<double*>(smem_raw);
+    double* csq = cs + (size_t)tile_k * DP;  // [tile_k]
+    unsigned long long* lsum = reinterpret_cast<unsigned long long*>(csq + tile_k);  // [k][d] when lds_acc
+    unsigned long long* lcnt = lsum + (size_t)k * d;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int j16 = lane & 15, g = lane >> 4;
+    const double scale = ACCUM ? st->scale : 0.0;
+    if constexpr (ACCUM) {
+        if (lds_acc)
+            for (int i = tid; i < k * (d + 1); i += kThreads) lsum[i] = 0ull;
+    }
+    const int64_t frames_per_wave = 16 * NF;
+    const int64_t n_units = (n + frames_per_wave - 1) / frames_per_wave;
+    const int waves_per_block = kThreads / 64;
+    // stage centre tile [k0, k0 + kt) and its squared norms (ascending-feature FMA chains)
+    auto stage_tile = [&](int k0, int kt, int kt16) {
+        for (int i = tid; i < kt16 * DP; i += kThreads) {
+            const int jt = i / (KS * 64);
+            const int rem = i - jt * (KS * 64);
+            const int s = rem >> 6, gg = (rem >> 4) & 3, jj = rem & 15;
+            const int j = jt * 16 + jj, f = 4 * s + gg;
+            cs[i] = (j < kt && f < d) ? centers[(size_t)(k0 + j) * d + f] : 0.0;
+        }
+        __syncthreads();
+        for (int j = tid; j < kt16; j += kThreads) {
+            double a = 0.0;
+            const double* cj = cs + (j >> 4) * KS * 64 + (j & 15);
+            for (int f = 0; f < d; ++f) {
+                const double c = cj[(f >> 2) * 64 + (f & 3) * 16];
+                a = fma(c, c, a);
+            }
+            csq[j] = j < kt ? a : __builtin_inf();  // padded centres can never win
+        }
+        __syncthreads();
+    };
+    const bool single_tile = k <= tile_k;  // the usual case: the tile is staged once per workgroup
+    if (single_tile) stage_tile(0, k, (k + 15) & ~15);
+    // all waves of a block walk the centre tiles together (shared LDS tile), each on its own frames
+    for (int64_t unit0 = (int64_t)blockIdx.x * waves_per_block; unit0 < n_units;
+         unit0 += (int64_t)gridDim.x * waves_per_block) {
+        const int64_t unit = unit0 + (tid >> 6);
+        double zb[NF][KS];
+        int64_t fidx[NF];
+#pragma unroll
+        for (int u = 0; u < NF; ++u) {
+            fidx[u] = unit * frames_per_wave + 16 * u + j16;
+            const bool ok = unit < n_units && fidx[u] < n;
+            const T* row = x + (ok ? fidx[u] : 0) * ld;
+#pragma unroll
+            for (int s = 0; s < KS; ++s) {
+                const int f = 4 * s + g;
+                double v = 0.0;
+                if (ok && f < d) {
+                    v = load_as_f64(row + f);
+                    if (mean) v = (v - mean[f]) / stdv[f];
+                }
+                zb[u][s] = v;
+            }
+        }
+        double best[NF];
+        int bidx[NF];
+#pragma unroll
+        for (int u = 0; u < NF; ++u) { best[u] = __builtin_inf(); bidx[u] = 0; }
+
+        for (int k0 = 0; k0 < k; k0 += tile_k) {
+            const int kt = min(tile_k, k - k0);
+            const int kt16 = (kt + 15) & ~15;
+            if (!single_tile) {
+                __syncthreads();  // previous tile fully consumed
+                stage_tile(k0, kt, kt16);
+            }
+            for (int jt = 0; jt < kt16 / 16; ++jt) {
+                double af[KS];
+#pragma unroll
+                for (int s = 0; s < KS; ++s) af[s] = cs[(jt * KS + s) * 64 + lane];
+                double cq[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) cq[r] = csq[jt * 16 + g + 4 * r];
+#pragma unroll
+                for (int u = 0; u < NF; ++u) {
+                    v4f64 acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                    for (int s = 0; s < KS; ++s) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(af[s], zb[u][s], acc, 0, 0, 0);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const double dist = fma(-2.0, acc[r], cq[r]);
+                        if (dist < best[u]) { best[u] = dist; bidx[u] = k0 + jt * 16 + g + 4 * r; }
+                    }
+                }
+            }
+        }
+        // merge the 4 candidates of each frame (lanes j16, j16+16, j16+32, j16+48)
+#pragma unroll
+        for (int u = 0; u < NF; ++u) {
+#pragma unroll
+            for (int off = 16; off < 64; off <<= 1) {
+                const double ob = __shfl_xor(best[u], off, 64);
+                const int oi = __shfl_xor(bidx[u], off, 64);
+                if (ob < best[u] || (ob == best[u] && oi < bidx[u])) { best[u] = ob; bidx[u] = oi; }
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < NF; ++u) {
+            const bool ok = unit < n_units && fidx[u] < n;
+            if (!ok) continue;
+            if constexpr (ACCUM) {
+                unsigned long long* srow = (lds_acc ? lsum : sums) + (size_t)bidx[u] * d;
+#pragma unroll
+                for (int s = 0; s < KS; ++s) {
+                    const int f = 4 * s + g;
+                    if (f < d) atomicAdd(&srow[f], (unsigned long long)to_fixed(zb[u][s], scale));
+                }
+                if (g == 0) atomicAdd((lds_acc ? lcnt : counts) + bidx[u], 1ull);
+            } else {
+                if (g == 0) {
+                    labels[fidx[u]] = bidx[u];
+                    if (mindist) {  // |z|^2 as the ascending-feature chain of the oracle
+                        const T* row = x + fidx[u] * ld;
+                        double zsq = 0.0;
+                        for (int f = 0; f < d; ++f) {
+                            double v = load_as_f64(row + f);
+                            if (mean) v = (v - mean[f]) / stdv[f];
+                            zsq = fma(v, v, zsq);
+                        }
+                        const double m = best[u] + zsq;
+                        mindist[fidx[u]] = m > 0.0 ? m : 0.0;
+                    }
+                }
+            }
+        }
+    }
+    if constexpr (ACCUM) {
+        if (lds_acc) {
+            __syncthreads();
+            for (int i = tid; i < k * d; i += kThreads)
+                if (lsum[i]) atomicAdd(&sums[i], lsum[i]);
+            for (int i = tid; i < k; i += kThreads)
+                if (lcnt[i]) atomicAdd(&counts[i], lcnt[i]);
+        }
+    }
+}
+
+template <typename T, int KS, bool ACCUM>
+msm_status launch_mfma(msm_ctx* ctx, const T* x, int64_t n, int d, int64_t ld, const double* centers, int k,
+                       const double* mean, const double* stdv, int32_t* labels, double* mindist, const FitState* st,
+                       unsigned long long* sums, unsigned long long* counts) {
+    constexpr int NF = KS <= 4 ? 4 : (KS <= 8 ? 2 : 1);
+    constexpr int DP = 4 * KS;
+    const size_t acc_bytes = ACCUM ? (size_t)k * (d + 1) * sizeof(unsigned long long) : 0;
+    const int lds_acc = ACCUM && acc_bytes <= 56 * 1024;
+    const size_t tile_budget = 72 * 1024 - (lds_acc ? acc_bytes : 0);  // 2 workgroups per CU
+    int tile_k = (int)(tile_budget / ((DP + 1) * sizeof(double))) & ~15;
+    const int k16 = (k + 15) & ~15;
+    if (tile_k > k16) tile_k = k16;
+    if (tile_k < 16) tile_k = 16;
+    const size_t lds = (size_t)tile_k * (DP + 1) * sizeof(double) + (lds_acc ? acc_bytes : 0);
+    const int64_t n_units = (n + 16 * NF - 1) / (16 * NF);
+    const int grid = (int)std::min<int64_t>((n_units + 3) / 4, (int64_t)ctx->n_cu * 2);
+    auto kern = kmeans_mfma_kernel<T, KS, NF, ACCUM>;
+    if (lds > 48 * 1024)
+        MSM_HIP(ctx, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(kThreads), lds, ctx->stream, x, n, d, ld, centers, k, mean, stdv, tile_k,
+                       labels, mindist, st, sums, counts, lds_acc);
+    MSM_CHECK_LAUNCH(ctx);
+    return MSM_OK;
+}
+
+template <typename T, bool ACCUM>
+msm_status dispatch_mfma(msm_ctx* ctx, const T* x, int64_t n, int d, int64_t ld, const double* centers, int k,
+                         const double* mean, const double* stdv, int32_t* labels, double* mindist, const FitState* st,
+                         unsigned long long* sums, unsigned long long* counts) {
+#define MSM_MFMA_CASE(KSV) \
+    if (d <= 4 * KSV)      \
+        return launch_mfma<T, KSV, ACCUM>(ctx, x, n, d, ld, centers, k, mean, stdv, labels, mindist, st, sums, counts)
+    MSM_MFMA_CASE(1);
+    MSM_MFMA_CASE(2);
+    MSM_MFMA_CASE(3);
+    MSM_MFMA_CASE(4);
+    MSM_MFMA_CASE(6);
+    MSM_MFMA_CASE(8);
+    MSM_MFMA_CASE(12);
+    MSM_MFMA_CASE(16);
+#undef MSM_MFMA_CASE
+    return msm_fail(ctx, MSM_ERR_UNSUPPORTED, "k-means: d=%d > 64 not supported yet", d);
+}
+
 template <typename T, int D, int R>
 msm_status launch_assign(msm_ctx* ctx, const T* x, int64_t n, int d, int64_t ld, const double* centers,
                          int k, const double* mean, const double* stdv, int32_t* labels, double* mindist) {
@@ -448,10 +664,10 @@ msm_status msm_kmeans_assign(msm_ctx* ctx, const void* d_x, msm_dtype dtype, int
     if (n == 0) return MSM_OK;
     MSM_REQUIRE(ctx, d_x && d_centers && d_labels, "msm_kmeans_assign: NULL pointer");
     if (dtype == MSM_F32)
-        return dispatch_assign<float>(ctx, (const float*)d_x, n, d, ld, d_centers, k, d_mean, d_std, d_labels,
-                                      d_mindist);
-    return dispatch_assign<double>(ctx, (const double*)d_x, n, d, ld, d_centers, k, d_mean, d_std, d_labels,
-                                   d_mindist);
+        return dispatch_mfma<float, false>(ctx, (const float*)d_x, n, d, ld, d_centers, k, d_mean, d_std, d_labels,
+                                           d_mindist, nullptr, nullptr, nullptr);
+    return dispatch_mfma<double, false>(ctx, (const double*)d_x, n, d, ld, d_centers, k, d_mean, d_std, d_labels,
+                                        d_mindist, nullptr, nullptr, nullptr);
 }
 
 
@@ -502,11 +718,12 @@ msm_status msm_kmeans_accumulate(msm_ctx* ctx, const void* d_x, msm_dtype dtype,
     if (n == 0) return MSM_OK;
     MSM_REQUIRE(ctx, d_x && d_centers && d_state && d_sums && d_counts, "msm_kmeans_accumulate: NULL pointer");
     if (dtype == MSM_F32)
-        return dispatch_accum<float>(ctx, (const float*)d_x, n, d, ld, d_centers, k, d_mean, d_std,
-                                     (const FitState*)d_state, (unsigned long long*)d_sums,
-                                     (unsigned long long*)d_counts);
-    return dispatch_accum<double>(ctx, (const double*)d_x, n, d, ld, d_centers, k, d_mean, d_std,
-                                  (const FitState*)d_state, (unsigned long long*)d_sums, (unsigned long long*)d_counts);
+        return dispatch_mfma<float, true>(ctx, (const float*)d_x, n, d, ld, d_centers, k, d_mean, d_std, nullptr,
+                                          nullptr, (const FitState*)d_state, (unsigned long long*)d_sums,
+                                          (unsigned long long*)d_counts);
+    return dispatch_mfma<double, true>(ctx, (const double*)d_x, n, d, ld, d_centers, k, d_mean, d_std, nullptr, nullptr,
+                                       (const FitState*)d_state, (unsigned long long*)d_sums,
+                                       (unsigned long long*)d_counts);
 }
 
 msm_status msm_kmeans_update(msm_ctx* ctx, int64_t* d_sums, int64_t* d_counts, int k, int d, double* d_centers,

@@ -120,6 +120,30 @@ __global__ void moments_finalize_kernel(const double* __restrict__ sums, const d
     if (count) count[f] = cnt;
 }
 
+// mean / divisor of reduction._preprocess from raw sums, entirely on the device:
+//   mean  = shift + S1/cnt
+//   sigma = sqrt((S2 - S1^2/cnt) / n_rows)      (NaNs were imputed with the mean: they add 0
+//           to the centred square sum but count in the divisor), sigma < 10 eps -> 1
+__global__ void standardise_params_kernel(const double* __restrict__ sums, const double* __restrict__ shift, int F,
+                                          double n_rows, int with_std, double* __restrict__ mean,
+                                          double* __restrict__ scale, double* __restrict__ inv_scale) {
+    const int f = blockIdx.x * blockDim.x + threadIdx.x;
+    if (f >= F) return;
+    const double cnt = sums[f], s1 = sums[F + f], s2 = sums[2 * F + f];
+    double m = 0.0, sd = 1.0;
+    if (cnt > 0.0) {
+        m = shift[f] + s1 / cnt;
+        if (with_std) {
+            const double var = (s2 - s1 * s1 / cnt) / n_rows;
+            sd = var > 0.0 ? sqrt(var) : 0.0;
+            if (sd < 10.0 * 2.220446049250313e-16) sd = 1.0;
+        }
+    }
+    mean[f] = m;
+    scale[f] = sd;
+    inv_scale[f] = 1.0 / sd;
+}
+
 // ---------------------------------------------------------------------------
 // project: Y[t][c] = sum_f ((x[t][f] - mu[f]) * inv_sigma[f] - m[f]) * W[f][c]
 // NaN inputs are imputed to the column mean (z = 0), as reduction._preprocess does.
@@ -326,6 +350,17 @@ msm_status msm_moments_finalize(msm_ctx* ctx, const double* d_sums, const double
     MSM_REQUIRE(ctx, d_sums && d_shift && d_mean && d_std, "msm_moments_finalize: NULL pointer");
     hipLaunchKernelGGL(moments_finalize_kernel, dim3(msm_ceil_div(F, 256)), dim3(256), 0, ctx->stream, d_sums, d_shift,
                        F, ddof, d_mean, d_std, d_count);
+    MSM_CHECK_LAUNCH(ctx);
+    return MSM_OK;
+}
+
+msm_status msm_standardise_params(msm_ctx* ctx, const double* d_sums, const double* d_shift, int F, double n_rows,
+                                  int with_std, double* d_mean, double* d_scale, double* d_inv_scale) {
+    if (!ctx) return MSM_ERR_INVALID;
+    MSM_REQUIRE(ctx, F >= 1 && n_rows >= 1.0, "msm_standardise_params: need F >= 1, n_rows >= 1");
+    MSM_REQUIRE(ctx, d_sums && d_shift && d_mean && d_scale && d_inv_scale, "msm_standardise_params: NULL pointer");
+    hipLaunchKernelGGL(standardise_params_kernel, dim3(msm_ceil_div(F, 256)), dim3(256), 0, ctx->stream, d_sums, d_shift,
+                       F, n_rows, with_std, d_mean, d_scale, d_inv_scale);
     MSM_CHECK_LAUNCH(ctx);
     return MSM_OK;
 }

@@ -303,17 +303,25 @@ class Engine:
         """Raw sums [cnt | S1 | S2] (3F f64) about `shift` (default: row 0) -> (sums, shift)."""
         n, F = x.shape
         sums = sums if sums is not None else self.empty((3 * F,), np.float64)
-        shift_out = self.empty((F,), np.float64)
+        shift_out = self.empty((F,), np.float64) if shift is None else None  # no allocation in steady state
         check(lib.msm_column_moments_partial(self.handle, x.ptr, _dtype_code(x.dtype), n, F, F,
                                              shift.ptr if shift is not None else None, sums.ptr,
-                                             shift_out.ptr), self.handle)
-        return sums, shift_out
+                                             shift_out.ptr if shift_out is not None else None), self.handle)
+        return sums, (shift_out if shift_out is not None else shift)
 
     def moments_finalize(self, sums: DeviceArray, shift: DeviceArray, F: int, ddof: int = 0):
         mean, std, cnt = (self.empty((F,), np.float64) for _ in range(3))
         check(lib.msm_moments_finalize(self.handle, sums.ptr, shift.ptr, F, int(ddof), mean.ptr, std.ptr,
                                        cnt.ptr), self.handle)
         return mean, std, cnt
+
+    def standardise_params(self, sums: DeviceArray, shift: DeviceArray, F: int, n_rows: float, with_std: bool = True,
+                           out=None):
+        """-> (mean, scale, inv_scale) device arrays [F]: the _preprocess parameters, no host sync."""
+        mean, scale, inv = out if out is not None else tuple(self.empty((F,), np.float64) for _ in range(3))
+        check(lib.msm_standardise_params(self.handle, sums.ptr, shift.ptr, F, float(n_rows), int(bool(with_std)),
+                                         mean.ptr, scale.ptr, inv.ptr), self.handle)
+        return mean, scale, inv
 
     def lagged_moments(self, x: DeviceArray, lag: int, shift: DeviceArray, *, starts=None, stops=None,
                        assume_finite: bool = False, out: DeviceArray | None = None) -> DeviceArray:

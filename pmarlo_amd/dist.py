@@ -1,0 +1,194 @@
+"""One trajectory shard per GPU: the hot path with all-reduce of the SMALL buffers only.
+
+Shards are independent trajectory segments (lag pairs never cross a shard),
+so the big arrays (features, projected coordinates, labels) never leave their GPU.  What is
+exchanged, by plain summation over RCCL/xGMI (``torch.distributed``, backend "nccl"):
+
+  exchange                      payload                         when
+  standardisation sums          3F f64                          once
+  lagged moments                2F^2 + 2F + 1 f64               once
+  k-means fixed-point scale     1 f64 (MIN) + centres bcast     once
+  k-means member sums / counts  k*d + k int64 (exact)           per Lloyd iteration
+  transition counts             k^2 int64 (exact)               once
+
+Integer payloads make the result independent of the number of shards bit for bit; the fp64
+moment sums are order-dependent only at the last bit across ranks.  With ``comm=None`` the
+same code runs on a single GPU (bench.py at N=1, tests).
+"""
+
+from __future__ import annotations
+
+from dataclasses import dataclass
+
+import numpy as np
+
+from .device import DeviceArray, Engine
+
+__all__ = ["Comm", "ShardedMSM", "ShardConfig"]
+
+
+class Comm:
+    """Reduction interface over device buffers.  ``TorchComm`` wraps torch.distributed; the
+    buffers it is given are views of torch tensors (see ``ShardedMSM.alloc``)."""
+
+    world = 1
+    rank = 0
+
+    def allreduce_sum(self, name: str) -> None: ...
+    def allreduce_min(self, name: str) -> None: ...
+    def allreduce_max(self, name: str) -> None: ...
+    def broadcast(self, name: str, src: int = 0) -> None: ...
+
+
+class TorchComm(Comm):
+    """torch.distributed collectives on named torch tensors (device or, for gloo tests, host)."""
+
+    def __init__(self, tensors: dict):
+        import torch.distributed as dist
+
+        self.dist = dist
+        self.t = tensors
+        self.world = dist.get_world_size()
+        self.rank = dist.get_rank()
+
+    def allreduce_sum(self, name):
+        self.dist.all_reduce(self.t[name], op=self.dist.ReduceOp.SUM)
+
+    def allreduce_min(self, name):
+        self.dist.all_reduce(self.t[name], op=self.dist.ReduceOp.MIN)
+
+    def allreduce_max(self, name):
+        self.dist.all_reduce(self.t[name], op=self.dist.ReduceOp.MAX)
+
+    def broadcast(self, name, src=0):
+        self.dist.broadcast(self.t[name], src=src)
+
+
+@dataclass
+class ShardConfig:
+    n_frames: int        # frames of THIS shard
+    n_features: int
+    tica_dim: int
+    k: int
+    lag: int
+    kmeans_iters: int = 10
+    seed: int = 0
+    n_total: int | None = None   # frames over all shards (defaults to n_frames * world)
+
+
+def exchange_shapes(cfg: ShardConfig) -> dict[str, tuple[tuple[int, ...], str]]:
+    """name -> (shape, dtype) of every buffer that crosses the interconnect."""
+    F, d, k = cfg.n_features, cfg.tica_dim, cfg.k
+    return {
+        "shift": ((F,), "float64"),
+        "mom_sums": ((3 * F,), "float64"),
+        "lagged": ((2 * F * F + 2 * F + 1,), "float64"),
+        "fit_state": ((8,), "float64"),
+        "centers": ((k, d), "float64"),
+        "km_acc": ((k * d + k,), "int64"),
+        "counts": ((k * k,), "int64"),
+        "pairs": ((1,), "int64"),
+    }
+
+
+class ShardedMSM:
+    """featurised shard -> TICA -> k-means -> counts -> T, device resident, one step = one pass."""
+
+    def __init__(self, engine: Engine, cfg: ShardConfig, x: DeviceArray, comm: Comm | None = None,
+                 shared: dict[str, DeviceArray] | None = None):
+        self.eng, self.cfg, self.x = engine, cfg, x
+        self.comm = comm
+        self.world = comm.world if comm else 1
+        self.n_total = cfg.n_total if cfg.n_total is not None else cfg.n_frames * self.world
+        eng = engine
+        F, d, k, n = cfg.n_features, cfg.tica_dim, cfg.k, cfg.n_frames
+        self.buf = shared if shared is not None else {
+            nm: eng.zeros(shape, np.dtype(dt)) for nm, (shape, dt) in exchange_shapes(cfg).items()}
+        b = self.buf
+        self.mean, self.scale, self.inv_scale = (eng.empty((F,), np.float64) for _ in range(3))
+        self.eig = eng.empty((F,), np.float64)
+        self.W = eng.empty((F, F), np.float64)
+        self.m2 = eng.empty((F,), np.float64)
+        self.rank_d = eng.empty((1,), np.int32)
+        self.Y = eng.empty((n, d), np.float64)
+        self.labels = eng.empty((n,), np.int32)
+        self.T = eng.empty((k, k), np.float64)
+        self.rowsum = eng.empty((k,), np.float64)
+        self.diag = eng.empty((1,), np.float64)
+        self.km_sums = b["km_acc"].view((k * d,), np.int64)
+        self.km_counts = b["km_acc"].view((k,), np.int64, offset_elems=k * d)
+        self.accum_events: list = []
+        self.time_accum = False
+        # one shift vector shared by all shards (row 0 of rank 0's shard) so that the raw
+        # moment sums add across ranks
+        _, first = eng.column_moments_partial(x)
+        check_d2d = first.to_host()
+        b["shift"].copy_from_host(check_d2d)
+        if comm and comm.world > 1:
+            comm.broadcast("shift", 0)
+
+    def step(self) -> None:
+        from ._lib import check, lib
+
+        eng, cfg, b, comm = self.eng, self.cfg, self.buf, self.comm
+        multi = comm is not None and comm.world > 1
+        F, d, k = cfg.n_features, cfg.tica_dim, cfg.k
+        # 1. standardisation moments
+        eng.column_moments_partial(self.x, shift=b["shift"], sums=b["mom_sums"])
+        if multi:
+            comm.allreduce_sum("mom_sums")
+        eng.standardise_params(b["mom_sums"], b["shift"], F, float(self.n_total), True,
+                               out=(self.mean, self.scale, self.inv_scale))
+        # 2. time-lagged covariance (fp64 MFMA) + TICA solve
+        eng.lagged_moments(self.x, cfg.lag, self.mean, assume_finite=True, out=b["lagged"])
+        if multi:
+            comm.allreduce_sum("lagged")
+        check(lib.msm_tica_solve(eng.handle, b["lagged"].ptr, self.scale.ptr, F, 1e-6, 1, self.eig.ptr, self.W.ptr,
+                                 self.m2.ptr, self.rank_d.ptr), eng.handle)
+        # 3. projection
+        eng.project(self.x, self.mean, self.inv_scale, self.W, d, mean2=self.m2, out=self.Y)
+        # 4. k-means: fixed number of Lloyd iterations over all frames
+        check(lib.msm_kmeans_fit_begin(eng.handle, self.Y.ptr, 1, cfg.n_frames, d, d, None, None, k, cfg.seed, 1,
+                                       float(self.n_total), 0.0, b["centers"].ptr, b["fit_state"].ptr), eng.handle)
+        if multi:
+            # identical start on every rank: rank 0's centres; the coarsest fixed-point scale
+            # (state = {scale, inv_scale, ...}: MIN of scale, inv_scale follows as MAX)
+            comm.broadcast("centers", 0)
+            comm.allreduce_min("fit_scale")
+            comm.allreduce_max("fit_inv_scale")
+        check(lib.msm_memset(eng.handle, b["km_acc"].ptr, 0, b["km_acc"].nbytes), eng.handle)
+        for _ in range(cfg.kmeans_iters):
+            if self.time_accum:
+                e0, e1 = eng.event(), eng.event()
+                e0.record()
+            eng.kmeans_accumulate(self.Y, b["centers"], b["fit_state"], self.km_sums, self.km_counts)
+            if self.time_accum:
+                e1.record()
+                self.accum_events.append((e0, e1))
+            if multi:
+                comm.allreduce_sum("km_acc")
+            eng.kmeans_update(self.km_sums, self.km_counts, b["centers"], b["fit_state"], clear=True)
+        eng.kmeans_assign(self.Y, b["centers"], labels=self.labels)
+        # 5. lag-tau counts + row-normalised transition matrix
+        eng.count_transitions(self.labels, k, cfg.lag, out=b["counts"].view((k, k)), pairs=b["pairs"])
+        if multi:
+            comm.allreduce_sum("counts")
+            comm.allreduce_sum("pairs")
+        check(lib.msm_transition_matrix(eng.handle, b["counts"].ptr, 0, k, 0, 0.0, 0.0, self.T.ptr, None, None, None,
+                                        self.rowsum.ptr, self.diag.ptr), eng.handle)
+
+
+def torch_exchange_buffers(engine: Engine, cfg: ShardConfig, device) -> tuple[dict, dict]:
+    """Allocate the exchange buffers as torch tensors on `device` (so torch.distributed can
+    reduce them) and return (tensors, DeviceArray views for the engine).  The two extra
+    entries "fit_scale" / "fit_inv_scale" alias elements 0 / 1 of "fit_state"."""
+    import torch
+
+    tensors, views = {}, {}
+    for name, (shape, dt) in exchange_shapes(cfg).items():
+        t = torch.zeros(shape, dtype=getattr(torch, dt), device=device)
+        tensors[name] = t
+        views[name] = engine.wrap(t.data_ptr(), shape, np.dtype(dt))
+    tensors["fit_scale"] = tensors["fit_state"][0:1]
+    tensors["fit_inv_scale"] = tensors["fit_state"][1:2]
+    return tensors, views
