@@ -11,13 +11,31 @@
 // 2 n (n+1) doubles fit; otherwise in global scratch.
 #include "common.h"
 
+// Diagnostic build only (tools/probe/jacobi_probe.hip): per-phase cycle stamps.
+#ifdef MSM_JACOBI_STAMPS
+__device__ unsigned long long g_jacobi_stamps[8];
+#define JSTAMP(i)                                                                          \
+    do {                                                                                   \
+        unsigned long long t__;                                                            \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t__)::"memory");       \
+        acc__[i] += t__ - last__;                                                          \
+        last__ = t__;                                                                      \
+    } while (0)
+#define JSTAMP_INIT unsigned long long acc__[8] = {0, 0, 0, 0, 0, 0, 0, 0}; unsigned long long last__; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(last__)::"memory");
+#define JSTAMP_FLUSH if (threadIdx.x == 0) { for (int i__ = 0; i__ < 8; ++i__) g_jacobi_stamps[i__] += acc__[i__]; }
+#else
+#define JSTAMP(i)
+#define JSTAMP_INIT
+#define JSTAMP_FLUSH
+#endif
+
 namespace {
 
 constexpr int kEigThreads = 1024;
 constexpr int kMaxPairs = 128;  // n <= 256
 
 struct JacobiShared {
-    double c[kMaxPairs], s[kMaxPairs];
+    double2 cs[kMaxPairs];  // (c, s) of pivot i: one 16-byte LDS read
     int p[kMaxPairs], q[kMaxPairs];
     double red[kEigThreads / 64];
     double bc[4];
@@ -64,36 +82,60 @@ __device__ __forceinline__ void jacobi_rotation(double app, double aqq, double a
     const double a = 0.5 * (aqq - app);
     const double h2 = fma(a, a, apq * apq);
     if (!(h2 > 1e-300) || !(h2 < 1e300)) return;  // degenerate scale: skip this pivot
-    const double h = h2 * nr_rsqrt(h2);
-    const double t = (a >= 0.0 ? apq : -apq) * nr_rcp(fabs(a) + h);
+    // h and 1/(|a|+h) only steer the angle: one Newton step (~1e-13 relative) is plenty, the
+    // pivot is zeroed explicitly; c below carries orthogonality and gets the full two steps.
+    double rh = __builtin_amdgcn_rsq(h2);
+    rh = rh * fma(-0.5 * h2 * rh, rh, 1.5);
+    const double h = h2 * rh;
+    const double den = fabs(a) + h;
+    double rd = __builtin_amdgcn_rcp(den);
+    rd = fma(rd, fma(-den, rd, 1.0), rd);
+    const double t = (a >= 0.0 ? apq : -apq) * rd;
     c = nr_rsqrt(fma(t, t, 1.0));
     s = t * c;
+}
+
+// Round-robin tournament: pivot i of round r pairs indices (p < q); index npad-1 is the
+// padding player when n is odd.  Pure integer arithmetic (cheaper than an LDS table: the
+// update phase is bound by LDS instruction issue).
+__device__ __forceinline__ void pivot_pair(int round, int i, int npad, int& p, int& q) {
+    int a, b;
+    if (i == 0) { a = npad - 1; b = round; }
+    else {
+        a = round + i; if (a >= npad - 1) a -= npad - 1;
+        b = round - i; if (b < 0) b += npad - 1;
+    }
+    p = min(a, b); q = max(a, b);
 }
 
 // A (n x n, row stride ld, symmetric) -> diagonal; V -> eigenvectors in columns.
 // Returns the number of sweeps used (uniform across the block).
 //
-// Work split: a wave owns pivots i = wave, wave + n_waves, ... of the round and its
-// lanes walk the row (then column) index, so (p, q, c, s) are wave-uniform values kept
-// in registers between the two phases: no parameter exchange, two barriers per round.
-// A wave may form its rotation right after the previous round's barrier because rows
-// p, q (which hold a_pp, a_qq, a_pq) are touched by no other pivot of the round.
-__device__ int jacobi_eigh(double* A, double* V, int n, int ld, JacobiShared* sh, int max_sweeps) {
+// One round = two phases, two barriers:
+//  (1) lane i of the first waves forms the rotation of pivot i -- all m = n/2 serial
+//      fp64 chains of the round run side by side (a lone dependent fp64 op costs ~44
+//      cycles on this chip, so the chain, not the flop count, sets the pace);
+//  (2) A <- J'AJ in ONE pass: the pivots partition the indices, so A splits into m x m
+//      disjoint 2x2 blocks (rows of pivot a, columns of pivot b) and block (a, b) needs
+//      only its own four entries and the two rotations -- no intermediate "rows done"
+//      barrier.  V <- VJ rides in the same phase.
+__device__ __forceinline__ int jacobi_eigh(double* A, double* V, int n, int ld, JacobiShared* sh, int max_sweeps) {
     const int tid = threadIdx.x, nt = blockDim.x;
-    const int lane = tid & 63, wave = tid >> 6, n_waves = nt >> 6;
     for (int i = tid; i < n * n; i += nt) V[(i / n) * ld + (i % n)] = (i / n == i % n) ? 1.0 : 0.0;
     __syncthreads();
     if (n < 2) return 0;
     const int npad = n + (n & 1);
     const int m = npad / 2;
     int sweep = 0;
+    JSTAMP_INIT
     for (; sweep < max_sweeps; ++sweep) {
+        JSTAMP(0);
         double off = 0.0, dia = 0.0;
-        for (int r = wave; r < n; r += n_waves)
-            for (int c = lane; c < n; c += 64) {
-                const double v = A[r * ld + c];
-                if (r == c) dia = fma(v, v, dia); else off = fma(v, v, off);
-            }
+        for (int i = tid; i < n * n; i += nt) {
+            const int r = i / n, c = i - r * n;
+            const double v = A[r * ld + c];
+            if (r == c) dia = fma(v, v, dia); else off = fma(v, v, off);
+        }
         off = block_sum(off, sh);
         dia = block_sum(dia, sh);
         // converged when ||off||_F <= n*eps*||A||_F: rounding of the rotations themselves
@@ -101,51 +143,111 @@ __device__ int jacobi_eigh(double* A, double* V, int n, int ld, JacobiShared* sh
         // is second order in it.
         const double tol = (double)n * 2.220446049250313e-16;
         if (off <= tol * tol * (dia + off) || off == 0.0) break;
+        JSTAMP(1);
+        // fast path: one 2x2 block and at most two V items per thread, indices fixed for the sweep
+        const bool fast = (m * m <= nt) && (m * n <= 2 * nt);
+        const int my_ia = tid / m, my_ib = tid - my_ia * m;
+        const bool has_blk = tid < m * m;
+        const int v_ib0 = tid / n, v_r0 = tid - v_ib0 * n;
+        const int v_ib1 = (tid + nt) / n, v_r1 = (tid + nt) - v_ib1 * n;
+        const bool has_v0 = tid < m * n, has_v1 = tid + nt < m * n;
+        // clamped copies keep every fast-path load in range for the threads without work
+        const int my_ia_c = has_blk ? my_ia : 0, my_ib_c = has_blk ? my_ib : 0;
+        const int v_ib0_c = has_v0 ? v_ib0 : 0, v_ib1_c = has_v1 ? v_ib1 : 0;
+        const int v_r1_c = has_v1 ? v_r1 : 0;
         for (int round = 0; round < npad - 1; ++round) {
-            // rows: A <- J' A   (rotation parameters parked in LDS for the column phase)
-#pragma unroll 1
-            for (int i = wave; i < m; i += n_waves) {
-                int a, b;
-                if (i == 0) { a = npad - 1; b = round; }
-                else { a = (round + i) % (npad - 1); b = (round - i + (npad - 1)) % (npad - 1); }
-                const int p = min(a, b), q = max(a, b);
-                if (q >= n) continue;  // padding pivot (odd n)
-                double c, s;
-                jacobi_rotation(A[p * ld + p], A[q * ld + q], A[p * ld + q], c, s);
-                if (lane == 0) { sh->c[i] = c; sh->s[i] = s; }
-                double* rp = A + p * ld;
-                double* rq = A + q * ld;
-                for (int j = lane; j < n; j += 64) {
-                    const double ap = rp[j], aq = rq[j];
-                    rp[j] = c * ap - s * aq;
-                    rq[j] = s * ap + c * aq;
+            if (tid < m) {
+                const int i = tid;
+                int p, q;
+                pivot_pair(round, i, npad, p, q);
+                double c = 1.0, s = 0.0;
+                if (q < n) jacobi_rotation(A[p * ld + p], A[q * ld + q], A[p * ld + q], c, s);
+                sh->cs[i] = make_double2(c, s); sh->p[i] = p; sh->q[i] = q;
+            }
+            JSTAMP(2);
+            __syncthreads();
+            JSTAMP(3);
+            if (fast) {
+                // Branch-free: every load uses an in-range (clamped) address and is issued
+                // before the first use; only the stores are predicated.  (Predicated LOADS
+                // made the compiler fence each one with s_waitcnt: ~20 exposed LDS latencies.)
+                int pa, qa, pb, qb, vp0, vq0, vp1, vq1;
+                pivot_pair(round, my_ia_c, npad, pa, qa);
+                pivot_pair(round, my_ib_c, npad, pb, qb);
+                pivot_pair(round, v_ib0_c, npad, vp0, vq0);
+                pivot_pair(round, v_ib1_c, npad, vp1, vq1);
+                const bool row_real = qa < n, col_real = qb < n, v0 = has_v0 && vq0 < n, v1 = has_v1 && vq1 < n;
+                const int qa_c = row_real ? qa : pa, qb_c = col_real ? qb : pb;
+                const int vq0_c = vq0 < n ? vq0 : vp0, vq1_c = vq1 < n ? vq1 : vp1;
+                const double2 ra = sh->cs[my_ia_c], rb = sh->cs[my_ib_c], r0 = sh->cs[v_ib0_c], r1 = sh->cs[v_ib1_c];
+                const double app = A[pa * ld + pb], apq = A[pa * ld + qb_c];
+                const double aqp = A[qa_c * ld + pb], aqq = A[qa_c * ld + qb_c];
+                const double x0p = V[v_r0 * ld + vp0], x0q = V[v_r0 * ld + vq0_c];
+                const double x1p = V[v_r1_c * ld + vp1], x1q = V[v_r1_c * ld + vq1_c];
+                // the index sitting out (odd n) is not rotated
+                const double ca = row_real ? ra.x : 1.0, sa = row_real ? ra.y : 0.0;
+                const double cb = col_real ? rb.x : 1.0, sb = col_real ? rb.y : 0.0;
+                const double rpp = fma(-sa, aqp, ca * app), rpq = fma(-sa, aqq, ca * apq);
+                const double rqp = fma(sa, app, ca * aqp), rqq = fma(sa, apq, ca * aqq);
+                double npp = fma(-sb, rpq, cb * rpp), npq = fma(sb, rpp, cb * rpq);
+                double nqp = fma(-sb, rqq, cb * rqp), nqq = fma(sb, rqp, cb * rqq);
+                if (my_ia_c == my_ib_c) { npq = 0.0; nqp = 0.0; }  // the pivot is annihilated exactly
+                const double y0p = fma(-r0.y, x0q, r0.x * x0p), y0q = fma(r0.y, x0p, r0.x * x0q);
+                const double y1p = fma(-r1.y, x1q, r1.x * x1p), y1q = fma(r1.y, x1p, r1.x * x1q);
+                if (has_blk) A[pa * ld + pb] = npp;
+                if (has_blk && col_real) A[pa * ld + qb] = npq;
+                if (has_blk && row_real) A[qa * ld + pb] = nqp;
+                if (has_blk && row_real && col_real) A[qa * ld + qb] = nqq;
+                if (v0) { V[v_r0 * ld + vp0] = y0p; V[v_r0 * ld + vq0] = y0q; }
+                if (v1) { V[v_r1_c * ld + vp1] = y1p; V[v_r1_c * ld + vq1] = y1q; }
+                JSTAMP(4);
+                JSTAMP(5);
+            } else {
+                for (int blk = tid; blk < m * m; blk += nt) {
+                    const int ia = blk / m, ib = blk - ia * m;
+                    const int pa = sh->p[ia], qa = sh->q[ia], pb = sh->p[ib], qb = sh->q[ib];
+                    const bool row_real = qa < n, col_real = qb < n;  // odd n: one index sits out each round
+                    if (!row_real && !col_real) continue;
+                    const double ca = sh->cs[ia].x, sa = sh->cs[ia].y, cb = sh->cs[ib].x, sb = sh->cs[ib].y;
+                    if (!col_real) {          // unpaired column pb: rows of pivot a only
+                        const double ap = A[pa * ld + pb], aq = A[qa * ld + pb];
+                        A[pa * ld + pb] = fma(-sa, aq, ca * ap);
+                        A[qa * ld + pb] = fma(sa, ap, ca * aq);
+                        continue;
+                    }
+                    if (!row_real) {          // unpaired row pa: columns of pivot b only
+                        const double ap = A[pa * ld + pb], aq = A[pa * ld + qb];
+                        A[pa * ld + pb] = fma(-sb, aq, cb * ap);
+                        A[pa * ld + qb] = fma(sb, ap, cb * aq);
+                        continue;
+                    }
+                    const double app = A[pa * ld + pb], apq = A[pa * ld + qb];
+                    const double aqp = A[qa * ld + pb], aqq = A[qa * ld + qb];
+                    const double rpp = fma(-sa, aqp, ca * app), rpq = fma(-sa, aqq, ca * apq);
+                    const double rqp = fma(sa, app, ca * aqp), rqq = fma(sa, apq, ca * aqq);
+                    double npp = fma(-sb, rpq, cb * rpp), npq = fma(sb, rpp, cb * rpq);
+                    double nqp = fma(-sb, rqq, cb * rqp), nqq = fma(sb, rqp, cb * rqq);
+                    if (ia == ib) { npq = 0.0; nqp = 0.0; }  // the pivot is annihilated exactly
+                    A[pa * ld + pb] = npp; A[pa * ld + qb] = npq;
+                    A[qa * ld + pb] = nqp; A[qa * ld + qb] = nqq;
                 }
+                JSTAMP(4);
+                for (int e = tid; e < m * n; e += nt) {
+                    const int ib = e / n, r = e - ib * n;
+                    const int pb = sh->p[ib], qb = sh->q[ib];
+                    if (qb >= n) continue;
+                    const double cb = sh->cs[ib].x, sb = sh->cs[ib].y;
+                    const double vp = V[r * ld + pb], vq = V[r * ld + qb];
+                    V[r * ld + pb] = fma(-sb, vq, cb * vp);
+                    V[r * ld + qb] = fma(sb, vp, cb * vq);
+                }
+                JSTAMP(5);
             }
             __syncthreads();
-            // columns: A <- A J, V <- V J; the pivot is annihilated exactly
-#pragma unroll 1
-            for (int i = wave; i < m; i += n_waves) {
-                int a, b;
-                if (i == 0) { a = npad - 1; b = round; }
-                else { a = (round + i) % (npad - 1); b = (round - i + (npad - 1)) % (npad - 1); }
-                const int p = min(a, b), q = max(a, b);
-                if (q >= n) continue;
-                const double c = sh->c[i], s = sh->s[i];
-                for (int r = lane; r < n; r += 64) {
-                    const double ap = A[r * ld + p], aq = A[r * ld + q];
-                    const double vp = V[r * ld + p], vq = V[r * ld + q];
-                    double np_ = c * ap - s * aq, nq_ = s * ap + c * aq;
-                    if (r == p) nq_ = 0.0;
-                    if (r == q) np_ = 0.0;
-                    A[r * ld + p] = np_;
-                    A[r * ld + q] = nq_;
-                    V[r * ld + p] = c * vp - s * vq;
-                    V[r * ld + q] = s * vp + c * vq;
-                }
-            }
-            __syncthreads();
+            JSTAMP(6);
         }
     }
+    JSTAMP_FLUSH
     return sweep;
 }
 
@@ -200,19 +302,20 @@ __device__ void small_mm(double* C, const double* A, bool transA, const double* 
 // moments = [M00 F*F][M0t F*F][sx F][sy F][T]   (centred by shift, unscaled)
 // scale   = per-feature divisor applied to the centred data (NULL -> 1)
 // lds_mats: how many of {A, V, B1, B2} live in LDS (4, 2 or 0)
+// (template, not a runtime flag: a pointer that may be LDS or global forces slow FLAT accesses)
+template <int lds_mats>
 __global__ __launch_bounds__(kEigThreads) void tica_solve_kernel(
     const double* __restrict__ mom, const double* __restrict__ scale, int n, int ld, double epsilon, int kinetic_map,
-    TicaWork wk, int lds_mats, double* __restrict__ out_eig, double* __restrict__ out_W, double* __restrict__ out_mean,
+    TicaWork wk, double* __restrict__ out_eig, double* __restrict__ out_W, double* __restrict__ out_mean,
     int* __restrict__ out_rank) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     __shared__ JacobiShared sh;
     const int tid = threadIdx.x, nt = blockDim.x;
     double* lds = reinterpret_cast<double*>(smem_raw);
     const size_t mat = (size_t)n * ld;
-    double* A = lds_mats >= 2 ? lds : wk.A;
-    double* V = lds_mats >= 2 ? lds + mat : wk.V;
-    double* B1 = lds_mats >= 4 ? lds + 2 * mat : wk.B1;
-    double* B2 = lds_mats >= 4 ? lds + 3 * mat : wk.B2;
+    double *A, *V, *B1, *B2;
+    if constexpr (lds_mats >= 2) { A = lds; V = lds + mat; } else { A = wk.A; V = wk.V; }
+    if constexpr (lds_mats >= 4) { B1 = lds + 2 * mat; B2 = lds + 3 * mat; } else { B1 = wk.B1; B2 = wk.B2; }
 
     const double* M00 = mom;
     const double* M0t = mom + (size_t)n * n;
@@ -312,15 +415,17 @@ __global__ __launch_bounds__(kEigThreads) void tica_solve_kernel(
 
 // Plain symmetric eigendecomposition (ascending eigenvalues), for tests and the
 // reversible MSM path.
+template <bool use_lds>
 __global__ __launch_bounds__(kEigThreads) void eigh_kernel(const double* __restrict__ Ain, int n, int ld,
-                                                          double* gA, double* gV, int use_lds, int* order,
+                                                          double* gA, double* gV, int* order,
                                                           double* __restrict__ out_w, double* __restrict__ out_v,
                                                           int* __restrict__ out_sweeps) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     __shared__ JacobiShared sh;
     const int tid = threadIdx.x, nt = blockDim.x;
-    double* A = use_lds ? reinterpret_cast<double*>(smem_raw) : gA;
-    double* V = use_lds ? A + (size_t)n * ld : gV;
+    double *A, *V;
+    if constexpr (use_lds) { A = reinterpret_cast<double*>(smem_raw); V = A + (size_t)n * ld; }
+    else { A = gA; V = gV; }
     for (int e = tid; e < n * n; e += nt) {
         const int i = e / n, j = e - i * n;
         A[i * ld + j] = 0.5 * (Ain[e] + Ain[j * n + i]);
@@ -373,11 +478,11 @@ msm_status msm_tica_solve(msm_ctx* ctx, const double* d_moments, const double* d
     if (4 * mat * sizeof(double) <= lds_budget) lds_mats = 4;
     else if (2 * mat * sizeof(double) <= lds_budget) lds_mats = 2;
     const size_t lds = (size_t)lds_mats * mat * sizeof(double);
+    auto kern = lds_mats == 4 ? tica_solve_kernel<4> : (lds_mats == 2 ? tica_solve_kernel<2> : tica_solve_kernel<0>);
     if (lds > 48 * 1024)
-        MSM_HIP(ctx, hipFuncSetAttribute((const void*)tica_solve_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                         (int)lds));
-    hipLaunchKernelGGL(tica_solve_kernel, dim3(1), dim3(kEigThreads), lds, ctx->stream, d_moments, d_scale, F, ld,
-                       epsilon, kinetic_map, wk, lds_mats, d_eigvals, d_coeffs, d_mean, d_rank);
+        MSM_HIP(ctx, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(kern, dim3(1), dim3(kEigThreads), lds, ctx->stream, d_moments, d_scale, F, ld, epsilon,
+                       kinetic_map, wk, d_eigvals, d_coeffs, d_mean, d_rank);
     MSM_CHECK_LAUNCH(ctx);
     return MSM_OK;
 }
@@ -395,10 +500,11 @@ msm_status msm_eigh(msm_ctx* ctx, const double* d_a, int n, double* d_w, double*
     int* order = (int*)(gV + mat);
     const size_t lds = jacobi_lds_bytes(n, ld);
     const int use_lds = lds <= 140 * 1024;
+    auto kern = use_lds ? eigh_kernel<true> : eigh_kernel<false>;
     if (use_lds && lds > 48 * 1024)
-        MSM_HIP(ctx, hipFuncSetAttribute((const void*)eigh_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(eigh_kernel, dim3(1), dim3(kEigThreads), use_lds ? lds : 0, ctx->stream, d_a, n, ld, gA, gV,
-                       use_lds, order, d_w, d_v, d_sweeps);
+        MSM_HIP(ctx, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(kern, dim3(1), dim3(kEigThreads), use_lds ? lds : 0, ctx->stream, d_a, n, ld, gA, gV, order,
+                       d_w, d_v, d_sweeps);
     MSM_CHECK_LAUNCH(ctx);
     return MSM_OK;
 }
