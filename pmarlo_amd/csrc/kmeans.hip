@@ -142,14 +142,25 @@ __global__ __launch_bounds__(kThreads) void absmax_kernel(const T* __restrict__ 
                                                          const double* __restrict__ stdv,
                                                          unsigned long long* __restrict__ out_bits) {
     double m = 0.0;
-    const int64_t total = n * d;
-    for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < total; i += (int64_t)gridDim.x * kThreads) {
-        const int64_t r = i / d;
-        const int f = (int)(i - r * d);
-        double v = (double)x[r * ld + f];
-        if (mean) v = (v - mean[f]) / stdv[f];
-        v = fabs(v);
-        if (v > m) m = v;  // NaN compares false: ignored
+    if (ld == d && !mean) {  // contiguous, no whitening: a flat stream, 4 loads in flight per lane
+        const int64_t total = n * d;
+        const int64_t step = (int64_t)gridDim.x * kThreads;
+        int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x;
+        for (; i + 3 * step < total; i += 4 * step) {
+            const double a = fabs((double)x[i]), b = fabs((double)x[i + step]);
+            const double c = fabs((double)x[i + 2 * step]), e = fabs((double)x[i + 3 * step]);
+            m = fmax(m, fmax(fmax(a, b), fmax(c, e)));  // fmax drops NaN operands
+        }
+        for (; i < total; i += step) m = fmax(m, fabs((double)x[i]));
+    } else {
+        const int64_t total = n * d;
+        for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < total; i += (int64_t)gridDim.x * kThreads) {
+            const int64_t r = i / d;
+            const int f = (int)(i - r * d);
+            double v = (double)x[r * ld + f];
+            if (mean) v = (v - mean[f]) / stdv[f];
+            m = fmax(m, fabs(v));
+        }
     }
     for (int off = 32; off > 0; off >>= 1) m = fmax(m, __shfl_down(m, off, 64));
     // non-negative doubles order like their bit patterns
@@ -412,9 +423,13 @@ msm_status dispatch_accum(msm_ctx* ctx, const T* x, int64_t n, int d, int64_t ld
 // frame merge their candidates (smaller distance, then smaller index) at the end.
 // ---------------------------------------------------------------------------
 typedef double v4f64 __attribute__((ext_vector_type(4)));
+// 8 waves share one LDS centre tile (+ the fixed-point accumulators): two waves per SIMD even
+// when tile + accumulators take ~100 KB, so one wave's arg-min VALU work hides under the
+// other's MFMAs.
+constexpr int kMT = 512;
 
 template <typename T, int KS, int NF, bool ACCUM>
-__global__ __launch_bounds__(kThreads, 2) void kmeans_mfma_kernel(
+__global__ __launch_bounds__(kMT, 2) void kmeans_mfma_kernel(
     const T* __restrict__ x, int64_t n, int d, int64_t ld, const double* __restrict__ centers, int k,
     const double* __restrict__ mean, const double* __restrict__ stdv, int tile_k /* multiple of 16 */,
     int32_t* __restrict__ labels, double* __restrict__ mindist, const FitState* __restrict__ st,
@@ -436,14 +451,14 @@ __global__ __launch_bounds__(kThreads, 2) void kmeans_mfma_kernel(
     const double scale = ACCUM ? st->scale : 0.0;
     if constexpr (ACCUM) {
         if (lds_acc)
-            for (int i = tid; i < k * (d + 1); i += kThreads) lsum[i] = 0ull;
+            for (int i = tid; i < k * (d + 1); i += kMT) lsum[i] = 0ull;
     }
     const int64_t frames_per_wave = 16 * NF;
     const int64_t n_units = (n + frames_per_wave - 1) / frames_per_wave;
-    const int waves_per_block = kThreads / 64;
+    const int waves_per_block = kMT / 64;
     // stage centre tile [k0, k0 + kt) and its squared norms (ascending-feature FMA chains)
     auto stage_tile = [&](int k0, int kt, int kt16) {
-        for (int i = tid; i < kt16 * DP; i += kThreads) {
+        for (int i = tid; i < kt16 * DP; i += kMT) {
             const int jt = i / (KS * 64);
             const int rem = i - jt * (KS * 64);
             const int s = rem >> 6, gg = (rem >> 4) & 3, jj = rem & 15;
@@ -451,7 +466,7 @@ __global__ __launch_bounds__(kThreads, 2) void kmeans_mfma_kernel(
             cs[i] = (j < kt && f < d) ? centers[(size_t)(k0 + j) * d + f] : 0.0;
         }
         __syncthreads();
-        for (int j = tid; j < kt16; j += kThreads) {
+        for (int j = tid; j < kt16; j += kMT) {
             double a = 0.0;
             const double* cj = cs + (j >> 4) * KS * 64 + (j & 15);
             for (int f = 0; f < d; ++f) {
@@ -561,9 +576,9 @@ __global__ __launch_bounds__(kThreads, 2) void kmeans_mfma_kernel(
     if constexpr (ACCUM) {
         if (lds_acc) {
             __syncthreads();
-            for (int i = tid; i < k * d; i += kThreads)
+            for (int i = tid; i < k * d; i += kMT)
                 if (lsum[i]) atomicAdd(&sums[i], lsum[i]);
-            for (int i = tid; i < k; i += kThreads)
+            for (int i = tid; i < k; i += kMT)
                 if (lcnt[i]) atomicAdd(&counts[i], lcnt[i]);
         }
     }
@@ -576,19 +591,20 @@ msm_status launch_mfma(msm_ctx* ctx, const T* x, int64_t n, int d, int64_t ld, c
     constexpr int NF = KS <= 4 ? 4 : (KS <= 8 ? 2 : 1);
     constexpr int DP = 4 * KS;
     const size_t acc_bytes = ACCUM ? (size_t)k * (d + 1) * sizeof(unsigned long long) : 0;
-    const int lds_acc = ACCUM && acc_bytes <= 56 * 1024;
-    const size_t tile_budget = 72 * 1024 - (lds_acc ? acc_bytes : 0);  // 2 workgroups per CU
+    const int lds_acc = ACCUM && acc_bytes <= 64 * 1024;
+    const size_t tile_budget = 150 * 1024 - (lds_acc ? acc_bytes : 0);  // one 8-wave workgroup per CU
     int tile_k = (int)(tile_budget / ((DP + 1) * sizeof(double))) & ~15;
     const int k16 = (k + 15) & ~15;
     if (tile_k > k16) tile_k = k16;
     if (tile_k < 16) tile_k = 16;
     const size_t lds = (size_t)tile_k * (DP + 1) * sizeof(double) + (lds_acc ? acc_bytes : 0);
     const int64_t n_units = (n + 16 * NF - 1) / (16 * NF);
-    const int grid = (int)std::min<int64_t>((n_units + 3) / 4, (int64_t)ctx->n_cu * 2);
+    const int waves = kMT / 64;
+    const int grid = (int)std::min<int64_t>((n_units + waves - 1) / waves, (int64_t)ctx->n_cu);
     auto kern = kmeans_mfma_kernel<T, KS, NF, ACCUM>;
     if (lds > 48 * 1024)
         MSM_HIP(ctx, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(kThreads), lds, ctx->stream, x, n, d, ld, centers, k, mean, stdv, tile_k,
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(kMT), lds, ctx->stream, x, n, d, ld, centers, k, mean, stdv, tile_k,
                        labels, mindist, st, sums, counts, lds_acc);
     MSM_CHECK_LAUNCH(ctx);
     return MSM_OK;

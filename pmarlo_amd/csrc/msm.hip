@@ -101,11 +101,17 @@ __global__ __launch_bounds__(kThreads) void build_T_kernel(const CT* __restrict_
         T[(size_t)a * k + b] = (cnt_as_f64(C[(size_t)ia * k + active[b]]) + alpha) / denom;
 }
 
-__global__ void diag_mass_kernel(const double* __restrict__ T, int k, double* __restrict__ out) {
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
-        double t = 0.0;
-        for (int i = 0; i < k; ++i) t += T[(size_t)i * k + i];
-        *out = k > 0 ? t / (double)k : __builtin_nan("");
+__global__ __launch_bounds__(1024) void diag_mass_kernel(const double* __restrict__ T, int k, double* __restrict__ out) {
+    __shared__ double red[16];
+    double t = 0.0;
+    for (int i = threadIdx.x; i < k; i += 1024) t += T[(size_t)i * k + i];
+    for (int off = 32; off > 0; off >>= 1) t += __shfl_down(t, off, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = t;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double s = 0.0;
+        for (int w = 0; w < 16; ++w) s += red[w];
+        *out = k > 0 ? s / (double)k : __builtin_nan("");
     }
 }
 
@@ -478,7 +484,7 @@ msm_status msm_transition_matrix(msm_ctx* ctx, const void* d_counts, int counts_
                            (const long long*)d_counts, k, mode, alpha, d_rowsum, d_active, d_n_active, d_T);
     MSM_CHECK_LAUNCH(ctx);
     if (d_diag_mass && mode == 0) {
-        hipLaunchKernelGGL(diag_mass_kernel, dim3(1), dim3(64), 0, ctx->stream, d_T, k, d_diag_mass);
+        hipLaunchKernelGGL(diag_mass_kernel, dim3(1), dim3(1024), 0, ctx->stream, d_T, k, d_diag_mass);
         MSM_CHECK_LAUNCH(ctx);
     }
     return MSM_OK;
