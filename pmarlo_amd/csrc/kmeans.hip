@@ -415,39 +415,61 @@ msm_status dispatch_accum(msm_ctx* ctx, const T* x, int64_t n, int d, int64_t ld
 //   B (frames) : lane l holds z[t0 + (l & 15)][4s + (l >> 4)]      (registers, loaded once)
 //   D          : lane l, reg r = dot[c0 + (l >> 4) + 4r][t0 + (l & 15)]
 // A wave keeps NF groups of 16 frames resident and walks all centre tiles, so each
-// A fragment feeds NF MFMAs.  With the accumulator starting at +0.0 and the k-steps
-// in ascending feature order the hardware's chain D = fma(a3,b3, fma(a2,b2, fma(a1,b1,
-// fma(a0,b0,C)))) is exactly the pinned ascending-feature FMA chain of the oracle
-// (padding features multiply 0 by 0), so labels stay bit-reproducible.  The VALU
-// only does dist = fma(-2, dot, |c|^2) and the running arg-min; the 4 lanes that share a
-// frame merge their candidates (smaller distance, then smaller index) at the end.
+// A fragment feeds NF MFMAs.  With the accumulator starting at +0.0 and the k-steps in
+// ascending feature order the hardware's chain fma(a3,b3, fma(a2,b2, fma(a1,b1, fma(a0,b0,C))))
+// is exactly the pinned ascending-feature FMA chain of the oracle (padding features multiply
+// 0 by 0), so labels stay bit-reproducible.
+//
+// Score.  The arg-min runs on  m = dot - |c|^2/2  (maximised): dist = fma(-2, dot, |c|^2) equals
+// -2 m EXACTLY (scaling by 2 commutes with rounding), so the order, the ties and the reported
+// distance are those of the pinned formula.  When d is not a multiple of 4 the spare k-slot
+// carries z = 1, c = -|c|^2/2, i.e. the MFMA chain itself ends with fma(1, -|c|^2/2, dot) = m and
+// the VALU does no arithmetic at all per pair.
+//
+// fp64 VALU instructions and fp64 MFMAs do NOT overlap on gfx950 (tools/probe/
+// kmeans_loop_probe.hip: time = MFMA time + VALU time at any interleaving), so the
+// per-tile epilogue is kept minimal: per 16 x 16 tile and lane only max-of-4, one compare and
+// the winning TILE id; the winner inside that tile (first maximum, ascending centre index) is
+// recovered once per frame group by re-evaluating the four candidates with the same FMA chain.
 // ---------------------------------------------------------------------------
 typedef double v4f64 __attribute__((ext_vector_type(4)));
 // 8 waves share one LDS centre tile (+ the fixed-point accumulators): two waves per SIMD even
-// when tile + accumulators take ~100 KB, so one wave's arg-min VALU work hides under the
-// other's MFMAs.
+// when tile + accumulators take ~100 KB.
 constexpr int kMT = 512;
 
-template <typename T, int KS, int NF, bool ACCUM>
+// one v_max_f64: fmax() would first canonicalise both operands (two more fp64 VALU ops each,
+// and fp64 VALU time adds to fp64 MFMA time on this chip); NaNs lose against numbers here too
+__device__ __forceinline__ double max_f64(double a, double b) {
+    double r;
+    asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+
+template <typename T, int KS, int NF, bool ACCUM, bool FOLD>
 __global__ __launch_bounds__(kMT, 2) void kmeans_mfma_kernel(
     const T* __restrict__ x, int64_t n, int d, int64_t ld, const double* __restrict__ centers, int k,
     const double* __restrict__ mean, const double* __restrict__ stdv, int tile_k /* multiple of 16 */,
     int32_t* __restrict__ labels, double* __restrict__ mindist, const FitState* __restrict__ st,
     unsigned long long* __restrict__ sums, unsigned long long* __restrict__ counts, int lds_acc) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    constexpr int DP = 4 * KS;
+    // centre tile, k-step major so that a wave's A read is one contiguous 512-byte run:
+    // cs[(j / 16) * TS + s * 64 + g * 16 + (j % 16)] = C[k0 + j][4s + g].  The tile stride TS
+    // is padded by one double: the winner-recovery step reads tiles chosen per lane, and a
+    // stride of 2 (mod 64) dwords spreads 32 different tiles over 32 different bank pairs
+    // (an unpadded 1536-byte stride put every tile on the same banks: 32-way conflicts).
+    constexpr int TS = KS * 64 + 1;
     if constexpr (ACCUM) {
         if (st->done != 0.0) return;
     }
-    // centre tile, k-step major so that a wave's A read is one contiguous 512-byte run:
-    // cs[(j / 16) * KS * 64 + s * 64 + g * 16 + (j % 16)] = C[k0 + j][4s + g]
     double* cs = reinterpret_cast<double*>(smem_raw);
-    double* csq = cs + (size_t)tile_k * DP;  // [tile_k]
-    unsigned long long* lsum = reinterpret_cast<unsigned long long*>(csq + tile_k);  // [k][d] when lds_acc
+    double* chalf = cs + (size_t)(tile_k / 16) * TS;  // [tile_k]  |c|^2 / 2  (+inf for padding centres)
+    unsigned long long* lsum = reinterpret_cast<unsigned long long*>(chalf + tile_k);  // [k][d] when lds_acc
     unsigned long long* lcnt = lsum + (size_t)k * d;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int j16 = lane & 15, g = lane >> 4;
+    constexpr bool fold = FOLD;              // (d & 3) != 0: spare k-slot at feature index d carries -|c|^2/2
+    const int fold_s = d >> 2, fold_g = d & 3;
     const double scale = ACCUM ? st->scale : 0.0;
     if constexpr (ACCUM) {
         if (lds_acc)
@@ -456,24 +478,27 @@ __global__ __launch_bounds__(kMT, 2) void kmeans_mfma_kernel(
     const int64_t frames_per_wave = 16 * NF;
     const int64_t n_units = (n + frames_per_wave - 1) / frames_per_wave;
     const int waves_per_block = kMT / 64;
-    // stage centre tile [k0, k0 + kt) and its squared norms (ascending-feature FMA chains)
+    // stage centre tile [k0, k0 + kt): coordinates, then |c|^2/2 (ascending-feature FMA chain),
+    // then (fold) the spare slot
     auto stage_tile = [&](int k0, int kt, int kt16) {
-        for (int i = tid; i < kt16 * DP; i += kMT) {
+        for (int i = tid; i < kt16 * 4 * KS; i += kMT) {
             const int jt = i / (KS * 64);
             const int rem = i - jt * (KS * 64);
             const int s = rem >> 6, gg = (rem >> 4) & 3, jj = rem & 15;
             const int j = jt * 16 + jj, f = 4 * s + gg;
-            cs[i] = (j < kt && f < d) ? centers[(size_t)(k0 + j) * d + f] : 0.0;
+            cs[jt * TS + rem] = (j < kt && f < d) ? centers[(size_t)(k0 + j) * d + f] : 0.0;
         }
         __syncthreads();
         for (int j = tid; j < kt16; j += kMT) {
             double a = 0.0;
-            const double* cj = cs + (j >> 4) * KS * 64 + (j & 15);
+            double* cj = cs + (j >> 4) * TS + (j & 15);
             for (int f = 0; f < d; ++f) {
                 const double c = cj[(f >> 2) * 64 + (f & 3) * 16];
                 a = fma(c, c, a);
             }
-            csq[j] = j < kt ? a : __builtin_inf();  // padded centres can never win
+            const double h = j < kt ? 0.5 * a : __builtin_inf();  // padding centres can never win
+            chalf[j] = h;
+            if (fold) cj[fold_s * 64 + fold_g * 16] = -h;
         }
         __syncthreads();
     };
@@ -485,26 +510,28 @@ __global__ __launch_bounds__(kMT, 2) void kmeans_mfma_kernel(
         const int64_t unit = unit0 + (tid >> 6);
         double zb[NF][KS];
         int64_t fidx[NF];
+        bool fok[NF];
 #pragma unroll
         for (int u = 0; u < NF; ++u) {
             fidx[u] = unit * frames_per_wave + 16 * u + j16;
-            const bool ok = unit < n_units && fidx[u] < n;
-            const T* row = x + (ok ? fidx[u] : 0) * ld;
+            fok[u] = unit < n_units && fidx[u] < n;
+            const T* row = x + (fok[u] ? fidx[u] : 0) * ld;
 #pragma unroll
             for (int s = 0; s < KS; ++s) {
                 const int f = 4 * s + g;
                 double v = 0.0;
-                if (ok && f < d) {
+                if (fok[u] && f < d) {
                     v = load_as_f64(row + f);
                     if (mean) v = (v - mean[f]) / stdv[f];
                 }
+                if (fold && s == fold_s && g == fold_g) v = 1.0;
                 zb[u][s] = v;
             }
         }
-        double best[NF];
-        int bidx[NF];
+        double bestm[NF];
+        int btile[NF];  // winning tile as a global centre offset (k0 + 16 jt)
 #pragma unroll
-        for (int u = 0; u < NF; ++u) { best[u] = __builtin_inf(); bidx[u] = 0; }
+        for (int u = 0; u < NF; ++u) { bestm[u] = -__builtin_inf(); btile[u] = 0; }
 
         for (int k0 = 0; k0 < k; k0 += tile_k) {
             const int kt = min(tile_k, k - k0);
@@ -513,40 +540,106 @@ __global__ __launch_bounds__(kMT, 2) void kmeans_mfma_kernel(
                 __syncthreads();  // previous tile fully consumed
                 stage_tile(k0, kt, kt16);
             }
-            for (int jt = 0; jt < kt16 / 16; ++jt) {
-                double af[KS];
+            const int n_tiles = kt16 / 16;
+            double af[KS], af_next[KS];
 #pragma unroll
-                for (int s = 0; s < KS; ++s) af[s] = cs[(jt * KS + s) * 64 + lane];
-                double cq[4];
+            for (int s = 0; s < KS; ++s) af[s] = cs[s * 64 + lane];
+            for (int jt = 0; jt < n_tiles; ++jt) {
+                // next tile's A fragment is fetched under this tile's MFMAs (clamped on the last)
+                const int jn = min(jt + 1, n_tiles - 1);
 #pragma unroll
-                for (int r = 0; r < 4; ++r) cq[r] = csq[jt * 16 + g + 4 * r];
+                for (int s = 0; s < KS; ++s) af_next[s] = cs[jn * TS + s * 64 + lane];
+                double ch[4] = {0.0, 0.0, 0.0, 0.0};
+                if constexpr (!fold) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) ch[r] = chalf[jt * 16 + g + 4 * r];
+                }
+                // all MFMAs of the tile first (independent chains interleaved), then the VALU:
+                // the first group's results are complete by the time its arg-max starts
+                v4f64 acc[NF];
+#pragma unroll
+                for (int u = 0; u < NF; ++u) acc[u] = (v4f64){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                for (int s = 0; s < KS; ++s)
+#pragma unroll
+                    for (int u = 0; u < NF; ++u)
+                        acc[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[s], zb[u][s], acc[u], 0, 0, 0);
+                // MFMA -> VALU read needs 18 wait states; hipcc pads for its own instructions
+                // but not for the inline-asm v_max_f64 below
+                __builtin_amdgcn_sched_barrier(0);
+                asm volatile("s_nop 15\n\ts_nop 3" ::: "memory");
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int u = 0; u < NF; ++u) {
-                    v4f64 acc = {0.0, 0.0, 0.0, 0.0};
+                    double m0 = acc[u][0], m1 = acc[u][1], m2 = acc[u][2], m3 = acc[u][3];
+                    if constexpr (!fold) { m0 -= ch[0]; m1 -= ch[1]; m2 -= ch[2]; m3 -= ch[3]; }
+                    const double m = max_f64(max_f64(m0, m1), max_f64(m2, m3));
+                    if (m > bestm[u]) { bestm[u] = m; btile[u] = k0 + jt * 16; }
+                }
 #pragma unroll
-                    for (int s = 0; s < KS; ++s) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(af[s], zb[u][s], acc, 0, 0, 0);
+                for (int s = 0; s < KS; ++s) af[s] = af_next[s];
+            }
+        }
+        // Recover the winner inside the winning tile: first maximum over r (ascending centre
+        // index), re-evaluated with the oracle's chain from the centre table (L2-resident).
+        int bidx[NF];
+#pragma unroll
+        for (int u = 0; u < NF; ++u) {
+            const T* row = x + (fok[u] ? fidx[u] : 0) * ld;
+            double mr[4] = {0.0, 0.0, 0.0, 0.0}, hr[4] = {0.0, 0.0, 0.0, 0.0};
+            if (single_tile) {  // candidates and their half-norms are still in the LDS tile;
+                // the frame's coordinates are gathered from the four lanes that hold them
+                const double* cj = cs + (btile[u] >> 4) * TS + g;  // + 4r + s*64 + g'*16
+#pragma unroll
+                for (int s = 0; s < KS; ++s)
+#pragma unroll
+                    for (int gp = 0; gp < 4; ++gp) {
+                        const double v = __shfl(zb[u][s], j16 + 16 * gp, 64);
+                        if (4 * s + gp < d) {  // skips zero padding and the folded slot
+                            const double* cf = cj + s * 64 + gp * 16;
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) mr[r] = fma(v, cf[4 * r], mr[r]);
+                        }
+                    }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) hr[r] = 2.0 * chalf[btile[u] + g + 4 * r];  // +inf for padding
+            } else {
+                for (int f = 0; f < d; ++f) {
+                    double v = load_as_f64(row + f);
+                    if (mean) v = (v - mean[f]) / stdv[f];
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        const double dist = fma(-2.0, acc[r], cq[r]);
-                        if (dist < best[u]) { best[u] = dist; bidx[u] = k0 + jt * 16 + g + 4 * r; }
+                        const int c = min(btile[u] + g + 4 * r, k - 1);
+                        const double cf = centers[(size_t)c * d + f];
+                        mr[r] = fma(v, cf, mr[r]);
+                        hr[r] = fma(cf, cf, hr[r]);
                     }
                 }
             }
+            double bm = -__builtin_inf();
+            int bi = btile[u] + g;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int c = btile[u] + g + 4 * r;
+                const double m = c < k ? mr[r] - 0.5 * hr[r] : -__builtin_inf();
+                if (m > bm) { bm = m; bi = c; }
+            }
+            bestm[u] = bm;
+            bidx[u] = bi;
         }
         // merge the 4 candidates of each frame (lanes j16, j16+16, j16+32, j16+48)
 #pragma unroll
         for (int u = 0; u < NF; ++u) {
 #pragma unroll
             for (int off = 16; off < 64; off <<= 1) {
-                const double ob = __shfl_xor(best[u], off, 64);
+                const double ob = __shfl_xor(bestm[u], off, 64);
                 const int oi = __shfl_xor(bidx[u], off, 64);
-                if (ob < best[u] || (ob == best[u] && oi < bidx[u])) { best[u] = ob; bidx[u] = oi; }
+                if (ob > bestm[u] || (ob == bestm[u] && oi < bidx[u])) { bestm[u] = ob; bidx[u] = oi; }
             }
         }
 #pragma unroll
         for (int u = 0; u < NF; ++u) {
-            const bool ok = unit < n_units && fidx[u] < n;
-            if (!ok) continue;
+            if (!fok[u]) continue;
             if constexpr (ACCUM) {
                 unsigned long long* srow = (lds_acc ? lsum : sums) + (size_t)bidx[u] * d;
 #pragma unroll
@@ -566,8 +659,8 @@ __global__ __launch_bounds__(kMT, 2) void kmeans_mfma_kernel(
                             if (mean) v = (v - mean[f]) / stdv[f];
                             zsq = fma(v, v, zsq);
                         }
-                        const double m = best[u] + zsq;
-                        mindist[fidx[u]] = m > 0.0 ? m : 0.0;
+                        const double md = -2.0 * bestm[u] + zsq;  // -2 m == fma(-2, dot, |c|^2) exactly
+                        mindist[fidx[u]] = md > 0.0 ? md : 0.0;
                     }
                 }
             }
@@ -589,19 +682,19 @@ msm_status launch_mfma(msm_ctx* ctx, const T* x, int64_t n, int d, int64_t ld, c
                        const double* mean, const double* stdv, int32_t* labels, double* mindist, const FitState* st,
                        unsigned long long* sums, unsigned long long* counts) {
     constexpr int NF = KS <= 4 ? 4 : (KS <= 8 ? 2 : 1);
-    constexpr int DP = 4 * KS;
+    constexpr int TS = KS * 64 + 1;  // doubles per 16-centre tile (see the kernel)
     const size_t acc_bytes = ACCUM ? (size_t)k * (d + 1) * sizeof(unsigned long long) : 0;
     const int lds_acc = ACCUM && acc_bytes <= 64 * 1024;
     const size_t tile_budget = 150 * 1024 - (lds_acc ? acc_bytes : 0);  // one 8-wave workgroup per CU
-    int tile_k = (int)(tile_budget / ((DP + 1) * sizeof(double))) & ~15;
+    int tile_k = (int)(tile_budget / ((TS + 16) * sizeof(double))) * 16;
     const int k16 = (k + 15) & ~15;
     if (tile_k > k16) tile_k = k16;
     if (tile_k < 16) tile_k = 16;
-    const size_t lds = (size_t)tile_k * (DP + 1) * sizeof(double) + (lds_acc ? acc_bytes : 0);
+    const size_t lds = (size_t)(tile_k / 16) * (TS + 16) * sizeof(double) + (lds_acc ? acc_bytes : 0);
     const int64_t n_units = (n + 16 * NF - 1) / (16 * NF);
     const int waves = kMT / 64;
     const int grid = (int)std::min<int64_t>((n_units + waves - 1) / waves, (int64_t)ctx->n_cu);
-    auto kern = kmeans_mfma_kernel<T, KS, NF, ACCUM>;
+    auto kern = (d & 3) != 0 ? kmeans_mfma_kernel<T, KS, NF, ACCUM, true> : kmeans_mfma_kernel<T, KS, NF, ACCUM, false>;
     if (lds > 48 * 1024)
         MSM_HIP(ctx, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(kern, dim3(grid), dim3(kMT), lds, ctx->stream, x, n, d, ld, centers, k, mean, stdv, tile_k,
