@@ -279,6 +279,44 @@ __device__ void canonical_signs(double* M, int n, int ncols, int ld) {
     __syncthreads();
 }
 
+// In-place Cholesky M = G G' (lower triangle of M becomes G).  Returns false (uniformly) as
+// soon as a pivot is not positive.  Block-parallel right-looking form, 3 barriers per column.
+__device__ bool cholesky_lower(double* M, int n, int ld, JacobiShared* sh) {
+    const int tid = threadIdx.x, nt = blockDim.x;
+    for (int j = 0; j < n; ++j) {
+        if (tid == 0) {
+            const double dj = M[j * ld + j];
+            sh->ibc[1] = dj > 0.0 ? 1 : 0;
+            if (dj > 0.0) M[j * ld + j] = sqrt(dj);
+        }
+        __syncthreads();
+        if (!sh->ibc[1]) return false;
+        const double gjj = M[j * ld + j];
+        for (int i = j + 1 + tid; i < n; i += nt) M[i * ld + j] /= gjj;
+        __syncthreads();
+        const int m = n - j - 1;
+        for (int e = tid; e < m * m; e += nt) {
+            const int a = e / m, b = e - a * m;  // trailing (j+1+a, j+1+b), lower part only
+            if (b <= a) M[(j + 1 + a) * ld + (j + 1 + b)] -= M[(j + 1 + a) * ld + j] * M[(j + 1 + b) * ld + j];
+        }
+        __syncthreads();
+    }
+    return true;
+}
+
+// X = G^-1 for lower-triangular G (one thread per column, forward substitution); X lower.
+__device__ void lower_inverse(const double* G, double* X, int n, int ld) {
+    for (int c = threadIdx.x; c < n; c += blockDim.x) {
+        for (int i = 0; i < c; ++i) X[i * ld + c] = 0.0;
+        for (int i = c; i < n; ++i) {
+            double sacc = (i == c) ? 1.0 : 0.0;
+            for (int k = c; k < i; ++k) sacc = fma(-G[i * ld + k], X[k * ld + c], sacc);
+            X[i * ld + c] = sacc / G[i * ld + i];
+        }
+    }
+    __syncthreads();
+}
+
 struct TicaWork {  // global scratch: four n*ld matrices, then ev[n], mean[n], isc[n], order[n]
     double *A, *V, *B1, *B2, *ev, *mean, *isc;
     int* order;
@@ -345,40 +383,70 @@ __global__ __launch_bounds__(kEigThreads) void tica_solve_kernel(
     }
     __syncthreads();
 
-    // ---- spd_inv_split(C00): eigh, sort by |ev| desc, cut at epsilon, canonical signs ----
-    jacobi_eigh(A, V, n, ld, &sh, 40);
-    for (int i = tid; i < n; i += nt) wk.ev[i] = A[i * ld + i];
-    __syncthreads();
-    sort_desc_abs(wk.ev, n, wk.order);
-    if (tid == 0) {
-        double evmin = wk.ev[0];
-        for (int i = 1; i < n; ++i) evmin = fmin(evmin, wk.ev[i]);
-        double eps = epsilon;
-        if (evmin < 0.0) eps = fmax(eps, -evmin + 1e-16);
-        int rank = 0;
-        for (int i = 0; i < n; ++i) rank += fabs(wk.ev[i]) >= eps;
-        sh.ibc[0] = rank;
-        *out_rank = rank;
+    // ---- whitening L with L' C00 L = I -------------------------------------------------
+    // deeptime's spd_inv_split keeps the eigen-directions of C00 with |s| >= epsilon.  When
+    // ALL of them qualify (C00 - epsilon I positive definite: tested by a Cholesky attempt)
+    // the TICA eigenpairs do not depend on which whitening is used -- they solve
+    // C0t r = lambda C00 r -- so L = chol(C00)^-T replaces the first Jacobi eigensolve
+    // (~15x cheaper).  Rank-deficient C00 takes the eigen path below, as before.
+    for (int e = tid; e < n * n; e += nt) {
+        const int i = e / n, j = e - i * n;
+        B2[i * ld + j] = A[i * ld + j] - (i == j ? epsilon : 0.0);
     }
     __syncthreads();
-    const int rank = sh.ibc[0];
-    if (rank == 0) {
-        for (int i = tid; i < n; i += nt) out_eig[i] = 0.0;
-        for (int i = tid; i < n * n; i += nt) out_W[i] = 0.0;
-        return;
+    const bool full_rank = cholesky_lower(B2, n, ld, &sh);
+    int rank;
+    if (full_rank) {
+        for (int e = tid; e < n * n; e += nt) {
+            const int i = e / n, j = e - i * n;
+            V[i * ld + j] = A[i * ld + j];
+        }
+        __syncthreads();
+        cholesky_lower(V, n, ld, &sh);      // C00 = G G'
+        lower_inverse(V, A, n, ld);         // A = G^-1 (lower)
+        for (int e = tid; e < n * n; e += nt) {
+            const int i = e / n, j = e - i * n;
+            B2[i * ld + j] = j >= i ? A[j * ld + i] : 0.0;  // L = G^-T (upper)
+        }
+        __syncthreads();
+        rank = n;
+        if (tid == 0) *out_rank = n;
+    } else {
+        // ---- spd_inv_split(C00): eigh, sort by |ev| desc, cut at epsilon, canonical signs ----
+        jacobi_eigh(A, V, n, ld, &sh, 40);
+        for (int i = tid; i < n; i += nt) wk.ev[i] = A[i * ld + i];
+        __syncthreads();
+        sort_desc_abs(wk.ev, n, wk.order);
+        if (tid == 0) {
+            double evmin = wk.ev[0];
+            for (int i = 1; i < n; ++i) evmin = fmin(evmin, wk.ev[i]);
+            double eps = epsilon;
+            if (evmin < 0.0) eps = fmax(eps, -evmin + 1e-16);
+            int rank = 0;
+            for (int i = 0; i < n; ++i) rank += fabs(wk.ev[i]) >= eps;
+            sh.ibc[0] = rank;
+            *out_rank = rank;
+        }
+        __syncthreads();
+        rank = sh.ibc[0];
+        if (rank == 0) {
+            for (int i = tid; i < n; i += nt) out_eig[i] = 0.0;
+            for (int i = tid; i < n * n; i += nt) out_W[i] = 0.0;
+            return;
+        }
+        // L (in B2) = V[:, order[:rank]] with canonical signs, columns scaled by 1/sqrt(s)
+        for (int e = tid; e < n * rank; e += nt) {
+            const int i = e / rank, j = e - i * rank;
+            B2[i * ld + j] = V[i * ld + wk.order[j]];
+        }
+        __syncthreads();
+        canonical_signs(B2, n, rank, ld);
+        for (int e = tid; e < n * rank; e += nt) {
+            const int i = e / rank, j = e - i * rank;
+            B2[i * ld + j] /= sqrt(wk.ev[wk.order[j]]);
+        }
+        __syncthreads();
     }
-    // L (in B2) = V[:, order[:rank]] with canonical signs, columns scaled by 1/sqrt(s)
-    for (int e = tid; e < n * rank; e += nt) {
-        const int i = e / rank, j = e - i * rank;
-        B2[i * ld + j] = V[i * ld + wk.order[j]];
-    }
-    __syncthreads();
-    canonical_signs(B2, n, rank, ld);
-    for (int e = tid; e < n * rank; e += nt) {
-        const int i = e / rank, j = e - i * rank;
-        B2[i * ld + j] /= sqrt(wk.ev[wk.order[j]]);
-    }
-    __syncthreads();
     // ---- Ct = L' C0t L: A <- C0t L, V <- L' A, A <- sym(V) ----
     small_mm(A, B1, false, B2, n, rank, n, ld);
     small_mm(V, B2, true, A, rank, rank, n, ld);
