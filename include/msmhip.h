@@ -201,7 +201,8 @@ msm_status msm_standardise_params(msm_ctx* ctx, const double* d_sums, const doub
  *   M00 = sum_{X0} z z' + sum_{Yt} z z',  M0t = sum_pairs z_t z_{t+lag}',
  *   sx / sy = column sums over X0 / Yt, T = number of pairs.
  * Un-normalised on purpose: shards all-reduce d_moments by summation
- * (they must share d_shift).  At most 16 segments per call; F <= 64.
+ * (they must share d_shift).  At most 16 segments per call.  F <= 64 runs the fused
+ * single-pass kernel; larger F the 64 x 64 block-task kernel.
  * assume_finite != 0 skips the NaN test (callers know from msm_column_moments'
  * d_count whether X holds NaNs; with NaNs present it must be 0). */
 msm_status msm_lagged_moments(msm_ctx* ctx, const void* d_x, msm_dtype dtype, int64_t n, int F, int64_t ld,

@@ -309,6 +309,216 @@ __global__ __launch_bounds__(1024) void cov_reduce_kernel(const double* __restri
     if (e == 0) sxy[2 * (size_t)F] = pairs;
 }
 
+// ---------------------------------------------------------------------------
+// F > 64: the F x F outputs are cut into 64 x 64 feature blocks; a workgroup computes ONE
+// block (16 tiles, 128 accumulator VGPRs per wave: two waves per SIMD without splitting) of
+// either M0t (bi, bj) or the upper triangle of M00 (bi <= bj) over its frame chunk.
+// grid = (frame chunks, block tasks).  Every task streams two 64-feature column blocks of X,
+// so X is re-read from L2 / Infinity Cache by the tasks that share a frame chunk.
+// ---------------------------------------------------------------------------
+constexpr int kBlkSlab = 16 * 256 + 2 * 64;  // doubles: 16 tiles + sx/sy of the 64 features
+
+template <typename T, bool VEC, bool FINITE>
+__global__ __launch_bounds__(256, 2) void cov_block_kernel(const T* __restrict__ x, int F, int64_t ld, FrameTab ft,
+                                                           const double* __restrict__ mu, int64_t frames_per_wave,
+                                                           int n_fb, double* __restrict__ slabs) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    double* red = reinterpret_cast<double*>(smem_raw);  // [16*256] + [4][2][4][64]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int fi_ = lane & 15, kk = lane >> 4;
+    const int lag = ft.lag;
+    // decode the block task
+    const int task = blockIdx.y;
+    int bi, bj;
+    bool is_00;
+    if (task < n_fb * n_fb) { is_00 = false; bi = task / n_fb; bj = task - bi * n_fb; }
+    else {
+        is_00 = true;
+        int s = task - n_fb * n_fb;
+        bi = 0;
+        while (s >= n_fb - bi) { s -= n_fb - bi; ++bi; }
+        bj = bi + s;
+    }
+    const bool diag = is_00 && bi == bj;
+    v4f64 acc[4][4];
+    double sx[4], sy[4], sha[4], shb[4];
+    bool foka[4], fokb[4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc[a][b] = (v4f64){0.0, 0.0, 0.0, 0.0};
+        sx[a] = sy[a] = 0.0;
+        const int fa = 64 * bi + 4 * fi_ + a, fb = 64 * bj + 4 * fi_ + a;
+        foka[a] = fa < F; fokb[a] = fb < F;
+        sha[a] = foka[a] ? mu[fa] : 0.0;
+        shb[a] = fokb[a] ? mu[fb] : 0.0;
+    }
+    const int64_t gw = (int64_t)blockIdx.x * 4 + wave;
+    const int64_t q_begin = gw * frames_per_wave;
+    const int64_t q_end = min(q_begin + frames_per_wave, ft.total);
+    using VT = T __attribute__((ext_vector_type(4)));
+    auto load_group = [&](int64_t t, int64_t s_start, int64_t s_stop, T (&ra)[4], T (&rb)[4], double& wx, double& wy) {
+        wx = (t + lag < s_stop) ? 1.0 : 0.0;
+        wy = (t < s_stop && t - lag >= s_start) ? 1.0 : 0.0;
+        const int64_t ta = min(t, s_stop - 1);
+        const int64_t tb = is_00 ? ta : min(t + lag, s_stop - 1);
+        const T* pa = x + ta * ld + 64 * bi + 4 * fi_;
+        const T* pb = x + tb * ld + 64 * bj + 4 * fi_;
+        if constexpr (VEC) {
+            const VT va = *reinterpret_cast<const VT*>(pa);
+            const VT vb = *reinterpret_cast<const VT*>(pb);
+#pragma unroll
+            for (int a = 0; a < 4; ++a) { ra[a] = va[a]; rb[a] = vb[a]; }
+        } else {
+#pragma unroll
+            for (int a = 0; a < 4; ++a) { ra[a] = foka[a] ? pa[a] : (T)0; rb[a] = fokb[a] ? pb[a] : (T)0; }
+        }
+    };
+    int seg = 0;
+    int64_t q0 = q_begin;
+    while (q0 < q_end) {
+        while (seg + 1 < ft.n && q0 >= ft.prefix[seg + 1]) ++seg;
+        const int64_t s_start = ft.start[seg], s_stop = ft.stop[seg];
+        const int64_t q_hi = min(q_end, ft.prefix[seg + 1]);
+        int64_t t = s_start + (q0 - ft.prefix[seg]) + kk;
+        T ra[4], rb[4];
+        double wx, wy;
+        load_group(t, s_start, s_stop, ra, rb, wx, wy);
+        for (; q0 < q_hi; q0 += 4) {
+            double za[4], zv[4];
+            const double wb = is_00 ? wx + wy : wx;  // B-side weight: [X0]+[Yt] for M00, [X0] for M0t
+#pragma unroll
+            for (int a = 0; a < 4; ++a) {
+                const double va = to_f64(ra[a]), vb = to_f64(rb[a]);
+                double ca = va - sha[a], cb = vb - shb[a];
+                if constexpr (!FINITE) {
+                    if (!(va == va)) ca = 0.0;
+                    if (!(vb == vb)) cb = 0.0;
+                }
+                if constexpr (!VEC) {
+                    if (!foka[a]) ca = 0.0;
+                    if (!fokb[a]) cb = 0.0;
+                }
+                za[a] = ca;
+                zv[a] = wb * cb;
+                if (diag) { sx[a] = fma(wx, ca, sx[a]); sy[a] = fma(wy, ca, sy[a]); }
+            }
+            t += 4;
+            if (q0 + 4 < q_hi) load_group(t, s_start, s_stop, ra, rb, wx, wy);
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int b = 0; b < 4; ++b)
+                    acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(za[a], zv[b], acc[a][b], 0, 0, 0);
+        }
+    }
+    double* sums = red + 16 * 256;  // [4][2][4][64]
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+        sums[((wave * 2 + 0) * 4 + a) * 64 + lane] = sx[a];
+        sums[((wave * 2 + 1) * 4 + a) * 64 + lane] = sy[a];
+    }
+    for (int w = 0; w < 4; ++w) {
+        if (wave == w) {
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int b = 0; b < 4; ++b)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int idx = ((a * 4 + b) * 4 + r) * 64 + lane;
+                        red[idx] = (w == 0 ? 0.0 : red[idx]) + acc[a][b][r];
+                    }
+        }
+        __syncthreads();
+    }
+    double* slab = slabs + ((size_t)task * gridDim.x + blockIdx.x) * kBlkSlab;
+    for (int i = tid; i < 16 * 256; i += 256) slab[i] = red[i];
+    if (tid < 128) {
+        const int which = tid >> 6, a = (tid >> 4) & 3, f = tid & 15;
+        double accs = 0.0;
+        for (int w = 0; w < 4; ++w)
+            for (int g = 0; g < 4; ++g) accs += sums[((w * 2 + which) * 4 + a) * 64 + g * 16 + f];
+        slab[16 * 256 + tid] = accs;
+    }
+}
+
+__global__ __launch_bounds__(1024) void cov_block_reduce_kernel(const double* __restrict__ slabs, int n_chunks, int F,
+                                                               int n_fb, double pairs, double* __restrict__ out) {
+    __shared__ double red[16][64];
+    const int io = threadIdx.x & 63, g = threadIdx.x >> 6;
+    const int task = blockIdx.y;
+    const int e = blockIdx.x * 64 + io;
+    double part = 0.0;
+    if (e < kBlkSlab)
+        for (int b = g; b < n_chunks; b += 16) part += slabs[((size_t)task * n_chunks + b) * kBlkSlab + e];
+    red[g][io] = part;
+    __syncthreads();
+    if (g != 0 || e >= kBlkSlab) return;
+    double acc = 0.0;
+    for (int q = 0; q < 16; ++q) acc += red[q][io];
+    int bi, bj;
+    bool is_00;
+    if (task < n_fb * n_fb) { is_00 = false; bi = task / n_fb; bj = task - bi * n_fb; }
+    else {
+        is_00 = true;
+        int s = task - n_fb * n_fb;
+        bi = 0;
+        while (s >= n_fb - bi) { s -= n_fb - bi; ++bi; }
+        bj = bi + s;
+    }
+    double* M00 = out;
+    double* M0t = out + (size_t)F * F;
+    double* sxy = M0t + (size_t)F * F;
+    if (e < 16 * 256) {
+        const int tile = e >> 8, r = (e >> 6) & 3, lane = e & 63;
+        const int a = tile >> 2, b = tile & 3;
+        const int row = 64 * bi + 4 * ((lane >> 4) + 4 * r) + a;   // f64 MFMA C/D layout + feature map
+        const int col = 64 * bj + 4 * (lane & 15) + b;
+        if (row < F && col < F) {
+            if (!is_00) M0t[(size_t)row * F + col] = acc;
+            else {
+                M00[(size_t)row * F + col] = acc;
+                if (bi != bj) M00[(size_t)col * F + row] = acc;
+            }
+        }
+    } else if (is_00 && bi == bj) {
+        const int i = e - 16 * 256;
+        const int which = i >> 6, a = (i >> 4) & 3, fi = i & 15;
+        const int f = 64 * bi + 4 * fi + a;
+        if (f < F) sxy[(size_t)which * F + f] = acc;
+    }
+    if (task == 0 && e == 0) sxy[2 * (size_t)F] = pairs;
+}
+
+template <typename T>
+msm_status launch_cov_blocked(msm_ctx* ctx, const T* x, int F, int64_t ld, const FrameTab& ft, const double* mu,
+                              bool finite, double* d_out) {
+    const int n_fb = (F + 63) / 64;
+    const int n_tasks = n_fb * n_fb + n_fb * (n_fb + 1) / 2;
+    int chunks = std::max(1, ctx->n_cu * 2 / n_tasks);
+    const int64_t groups = ft.total / kGroup;
+    if ((int64_t)chunks * 4 * 4 > groups) chunks = (int)std::max<int64_t>(1, groups / 16);
+    int64_t fpw = (ft.total + (int64_t)chunks * 4 - 1) / ((int64_t)chunks * 4);
+    fpw = (fpw + kGroup - 1) / kGroup * kGroup;
+    chunks = (int)((ft.total + fpw * 4 - 1) / (fpw * 4));
+    msm_status rs = msm_reserve_scratch(ctx, (size_t)n_tasks * chunks * kBlkSlab * sizeof(double));
+    if (rs != MSM_OK) return rs;
+    const size_t lds = ((size_t)16 * 256 + 4 * 2 * 4 * 64) * sizeof(double);
+    const bool vec = (F % 64 == 0) && (ld % 4 == 0) && (((uintptr_t)x) % (4 * sizeof(T)) == 0);
+    auto kern = vec ? (finite ? cov_block_kernel<T, true, true> : cov_block_kernel<T, true, false>)
+                    : (finite ? cov_block_kernel<T, false, true> : cov_block_kernel<T, false, false>);
+    MSM_HIP(ctx, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(kern, dim3(chunks, n_tasks), dim3(256), lds, ctx->stream, x, F, ld, ft, mu, fpw, n_fb,
+                       (double*)ctx->scratch);
+    MSM_CHECK_LAUNCH(ctx);
+    hipLaunchKernelGGL(cov_block_reduce_kernel, dim3(msm_ceil_div(kBlkSlab, 64), n_tasks), dim3(1024), 0, ctx->stream,
+                       (const double*)ctx->scratch, chunks, F, n_fb, (double)ft.pairs, d_out);
+    MSM_CHECK_LAUNCH(ctx);
+    return MSM_OK;
+}
+
 msm_status build_frametab(msm_ctx* ctx, int64_t n, const int64_t* h_start, const int64_t* h_stop, int n_seg, int lag,
                           FrameTab* out) {
     MSM_REQUIRE(ctx, lag >= 1, "lag must be >= 1 (got %d)", lag);
@@ -374,7 +584,7 @@ msm_status dispatch_cov(msm_ctx* ctx, const T* x, int F, int64_t ld, const Frame
     if (F <= 32) return launch_cov<T, 2>(ctx, x, F, ld, ft, mu, finite, d_out);
     if (F <= 48) return launch_cov<T, 3>(ctx, x, F, ld, ft, mu, finite, d_out);
     if (F <= 64) return launch_cov<T, 4>(ctx, x, F, ld, ft, mu, finite, d_out);
-    return msm_fail(ctx, MSM_ERR_UNSUPPORTED, "msm_lagged_moments: F=%d > 64 not supported yet", F);
+    return launch_cov_blocked<T>(ctx, x, F, ld, ft, mu, finite, d_out);
 }
 
 }  // namespace

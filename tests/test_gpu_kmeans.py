@@ -87,3 +87,15 @@ def test_assignment_is_argmin_of_true_distance(engine):
     d2 = ((Xs[:, None, :] - centers[None, :, :]) ** 2).sum(-1)
     np.testing.assert_allclose(d2[np.arange(idx.size), lab[idx]], d2.min(axis=1), rtol=1e-9, atol=1e-12)
     np.testing.assert_allclose(md[idx], d2.min(axis=1), rtol=1e-6, atol=1e-9)
+
+
+def test_assign_c5_cluster_count_multi_tile(engine):
+    """k = 2000 centres do not fit one LDS tile: the staged multi-tile path must agree too."""
+    n, d, k = 30_000, 10, 2000
+    X = _gen.correlated_series(n, d, seed=8).astype(np.float64)
+    rng = np.random.default_rng(1)
+    centers = X[rng.choice(n, k, replace=False)] + 1e-6 * rng.normal(size=(k, d))
+    want, md_want = cport.kmeans_assign(X, centers, want_mindist=True)
+    got, md = _assign(engine, X, centers, want_md=True)
+    np.testing.assert_array_equal(got, want)
+    np.testing.assert_array_equal(md, md_want)

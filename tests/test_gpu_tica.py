@@ -217,3 +217,46 @@ def test_project_matches_numpy(engine):
                        mean2=engine.to_device(m2)).to_host()
     want = ((X.astype(np.float64) - mu) * isg - m2) @ W[:, :d]
     np.testing.assert_allclose(Y, want, rtol=1e-12, atol=1e-12)
+
+
+@pytest.mark.parametrize("n,F,lag,dtype,segs", [
+    (6_000, 128, 5, np.float32, None),
+    (5_000, 256, 10, np.float32, [(0, 1777), (1777, 5000)]),      # C5 feature count
+    (3_000, 100, 3, np.float64, None),                            # not a multiple of 64: guarded path
+    (2_000, 65, 2, np.float32, None)])
+def test_lagged_moments_blocked_large_F(engine, n, F, lag, dtype, segs):
+    X = _gen.correlated_series(n, F, seed=F).astype(dtype)
+    X64 = X.astype(np.float64)
+    shift = X64.mean(axis=0)
+    kw = {}
+    seg_list = segs or [(0, n)]
+    if segs:
+        kw["starts"], kw["stops"] = _bounds(segs)
+    mom = engine.lagged_moments(engine.to_device(X), lag, engine.to_device(shift), **kw).to_host()
+    want = npport.lagged_moments([X64[a:b] - shift for a, b in seg_list], lag)
+    M00 = mom[:F * F].reshape(F, F)
+    M0t = mom[F * F:2 * F * F].reshape(F, F)
+    scale = np.abs(want["Mxx"]).max()
+    np.testing.assert_allclose(M00, want["Mxx"], rtol=0, atol=1e-12 * scale)
+    np.testing.assert_allclose(M0t, want["Mxy_half"], rtol=0, atol=1e-12 * scale)
+    sum_abs = np.abs(X64 - shift).sum(axis=0).max()
+    np.testing.assert_allclose(mom[2 * F * F:2 * F * F + F], want["sx"], rtol=0, atol=1e-13 * sum_abs)
+    np.testing.assert_allclose(mom[2 * F * F + F:2 * F * F + 2 * F], want["sy"], rtol=0, atol=1e-13 * sum_abs)
+    assert mom[-1] == want["T"]
+    np.testing.assert_array_equal(M00, M00.T)
+
+
+def test_tica_pipeline_c5_feature_count(engine):
+    """C5 shape at reduced N: F = 256 features -> TICA (block-task covariance, global-memory
+    Jacobi) -> projection, against the restated deeptime estimator."""
+    n, F, lag, dim = 20_000, 256, 10, 10
+    X = _gen.correlated_series(n, F, seed=5)
+    eig, W, m2, rank, Y = _tica_gpu(engine, X, lag, dim)
+    Xp = npport.preprocess(X, scale=True)
+    model = npport.tica_fit([Xp], lag, dim=dim)
+    assert rank == model["rank"] == F
+    np.testing.assert_allclose(eig[:dim], model["eigenvalues"][:dim], rtol=1e-8, atol=1e-10)
+    Yo = npport.tica_transform(model, Xp)
+    for c in range(3):  # the resolved slow modes; the noise modes are near-degenerate at this N
+        s = np.sign(np.dot(Y[:, c], Yo[:, c])) or 1.0
+        np.testing.assert_allclose(s * Y[:, c], Yo[:, c], atol=1e-7 * max(1.0, np.abs(Yo[:, c]).max()))
