@@ -583,27 +583,42 @@ __global__ __launch_bounds__(kMT, 2) void kmeans_mfma_kernel(
         // Recover the winner inside the winning tile: first maximum over r (ascending centre
         // index), re-evaluated with the oracle's chain from the centre table (L2-resident).
         int bidx[NF];
+        double mr[NF][4], hr[NF][4];
 #pragma unroll
-        for (int u = 0; u < NF; ++u) {
-            const T* row = x + (fok[u] ? fidx[u] : 0) * ld;
-            double mr[4] = {0.0, 0.0, 0.0, 0.0}, hr[4] = {0.0, 0.0, 0.0, 0.0};
-            if (single_tile) {  // candidates and their half-norms are still in the LDS tile;
-                // the frame's coordinates are gathered from the four lanes that hold them
-                const double* cj = cs + (btile[u] >> 4) * TS + g;  // + 4r + s*64 + g'*16
+        for (int u = 0; u < NF; ++u)
 #pragma unroll
-                for (int s = 0; s < KS; ++s)
+            for (int r = 0; r < 4; ++r) { mr[u][r] = 0.0; hr[u][r] = 0.0; }
+        if (single_tile) {
+            // candidates and their half-norms are still in the LDS tile; the frame's coordinates
+            // are gathered from the four lanes that hold them.  All NF x 4 chains advance together:
+            // a lone dependent fp64 FMA costs ~44 cycles, sixteen independent ones pipeline.
+            const double* cj[NF];
 #pragma unroll
-                    for (int gp = 0; gp < 4; ++gp) {
-                        const double v = __shfl(zb[u][s], j16 + 16 * gp, 64);
-                        if (4 * s + gp < d) {  // skips zero padding and the folded slot
-                            const double* cf = cj + s * 64 + gp * 16;
+            for (int u = 0; u < NF; ++u) cj[u] = cs + (btile[u] >> 4) * TS + g;  // + 4r + s*64 + g'*16
 #pragma unroll
-                            for (int r = 0; r < 4; ++r) mr[r] = fma(v, cf[4 * r], mr[r]);
+            for (int s = 0; s < KS; ++s)
+#pragma unroll
+                for (int gp = 0; gp < 4; ++gp) {
+                    double v[NF];
+#pragma unroll
+                    for (int u = 0; u < NF; ++u) v[u] = __shfl(zb[u][s], j16 + 16 * gp, 64);
+                    if (4 * s + gp < d) {  // skips zero padding and the folded slot
+#pragma unroll
+                        for (int u = 0; u < NF; ++u) {
+                            const double* cf = cj[u] + s * 64 + gp * 16;
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) mr[u][r] = fma(v[u], cf[4 * r], mr[u][r]);
                         }
                     }
+                }
 #pragma unroll
-                for (int r = 0; r < 4; ++r) hr[r] = 2.0 * chalf[btile[u] + g + 4 * r];  // +inf for padding
-            } else {
+            for (int u = 0; u < NF; ++u)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) hr[u][r] = 2.0 * chalf[btile[u] + g + 4 * r];  // +inf for padding
+        } else {
+#pragma unroll
+            for (int u = 0; u < NF; ++u) {
+                const T* row = x + (fok[u] ? fidx[u] : 0) * ld;
                 for (int f = 0; f < d; ++f) {
                     double v = load_as_f64(row + f);
                     if (mean) v = (v - mean[f]) / stdv[f];
@@ -611,17 +626,20 @@ __global__ __launch_bounds__(kMT, 2) void kmeans_mfma_kernel(
                     for (int r = 0; r < 4; ++r) {
                         const int c = min(btile[u] + g + 4 * r, k - 1);
                         const double cf = centers[(size_t)c * d + f];
-                        mr[r] = fma(v, cf, mr[r]);
-                        hr[r] = fma(cf, cf, hr[r]);
+                        mr[u][r] = fma(v, cf, mr[u][r]);
+                        hr[u][r] = fma(cf, cf, hr[u][r]);
                     }
                 }
             }
+        }
+#pragma unroll
+        for (int u = 0; u < NF; ++u) {
             double bm = -__builtin_inf();
             int bi = btile[u] + g;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int c = btile[u] + g + 4 * r;
-                const double m = c < k ? mr[r] - 0.5 * hr[r] : -__builtin_inf();
+                const double m = c < k ? mr[u][r] - 0.5 * hr[u][r] : -__builtin_inf();
                 if (m > bm) { bm = m; bi = c; }
             }
             bestm[u] = bm;
