@@ -87,9 +87,18 @@ def main() -> None:
         import torch
         import torch.distributed as dist
 
+        # rehearsal knobs (a one-GPU box cannot host two RCCL ranks): BENCH_BACKEND=gloo and
+        # BENCH_SAME_GPU=1 run every rank on device 0 with gloo moving the (device) buffers
+        backend = os.environ.get("BENCH_BACKEND", "nccl")
+        if os.environ.get("BENCH_SAME_GPU") == "1":
+            local_rank = 0
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl")
-        eng = Engine(local_rank, stream=torch.cuda.current_stream().cuda_stream)
+        dist.init_process_group(backend)
+        # one explicit stream shared by the engine's kernels and torch's collectives (the default
+        # stream's handle is 0, which the C ABI reads as "create your own stream")
+        stream = torch.cuda.Stream(device=local_rank)
+        torch.cuda.set_stream(stream)
+        eng = Engine(local_rank, stream=stream.cuda_stream)
     else:
         eng = Engine(local_rank)
 
@@ -179,6 +188,19 @@ def main() -> None:
             parity["its_timescales_frames"] = spec["its_ts"][0].tolist()
             parity["its_residual"] = float(spec["residual"][0])
             parity["tica_eigenvalues"] = msm.eig.to_host()[:TICA_DIM].tolist()
+            parity["tica_rank"] = int(msm.rank_d.to_host()[0])
+            if multi and n * world <= 2_000_000:
+                # rank 0 regenerates every shard (seeded) and checks the all-reduced TICA against the
+                # oracle on the list of shards (pairs never cross a shard)
+                shards = [npport.preprocess(np.vstack([_gen.correlated_series(n, N_FEATURES, seed=1000 + r)
+                                                       for r in range(world)]), scale=True)]
+                parts = [shards[0][r * n:(r + 1) * n] for r in range(world)]
+                ref = npport.tica_fit(parts, LAG, dim=TICA_DIM)
+                got = np.asarray(parity["tica_eigenvalues"])
+                m = min(2 * world, TICA_DIM)  # the resolved slow modes (2 per independently mixed shard)
+                parity["tica_eig_rel_err"] = float(np.max(np.abs(got[:m] - ref["eigenvalues"][:m])
+                                                          / np.abs(ref["eigenvalues"][:m])))
+                parity["tica_rank_oracle"] = int(ref["rank"])
         except Exception as exc:  # parity reporting must not hide the throughput line
             parity["error"] = repr(exc)
         out["parity"] = parity
