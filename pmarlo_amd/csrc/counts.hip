@@ -13,7 +13,7 @@
 
 namespace {
 
-constexpr int kThreads = 256;
+constexpr int kThreads = 1024;  // 16 waves per CU hide the label-load latency (one 128 KB workgroup per CU)
 constexpr int kLdsBudgetSmall = 64 * 1024;   // 2 workgroups / CU
 constexpr int kLdsBudgetLarge = 128 * 1024;  // 1 workgroup / CU
 constexpr int kMaxRowBlocks = 16;
@@ -27,6 +27,20 @@ __device__ __forceinline__ unsigned long long wave_sum_u64(unsigned long long v)
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
     return v;
+}
+
+// One same-address global atomic per WORKGROUP: thousands of per-wave atomics on one counter
+// serialise in L2 and used to cost more than the whole binning pass.
+__device__ __forceinline__ void block_add_u64(unsigned long long v, unsigned long long* dst) {
+    __shared__ unsigned long long wave_part[kThreads / 64];
+    v = wave_sum_u64(v);
+    if ((threadIdx.x & 63) == 0) wave_part[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned long long t = 0;
+        for (int w = 0; w < kThreads / 64; ++w) t += wave_part[w];
+        if (t) atomicAdd(dst, t);
+    }
 }
 
 // One lag.  grid = (chunks, row_blocks).
@@ -51,16 +65,28 @@ __global__ __launch_bounds__(kThreads) void count_lds_kernel(
     const int64_t p1 = min(p0 + pairs_per_chunk, st.total_pairs);
     const int lag = st.lag;
     unsigned long long local_pairs = 0;
-    for (int64_t p = p0 + tid; p < p1; p += kThreads) {
-        const int64_t t = seg_pair_to_frame(st, p);
-        const int a = labels[t];
-        const int b = labels[t + lag];
+    auto bin_pair = [&](int a, int b, int64_t t) {
         const int ra = a - r0;
         if ((unsigned)b < (unsigned)k && (unsigned)ra < (unsigned)nrows) {
             if constexpr (WEIGHTED) atomicAdd(&bins[ra * k + b], weights[t]);
             else atomicAdd(&bins[ra * k + b], 1u);
             ++local_pairs;
         }
+    };
+    int64_t p = p0 + tid;
+    for (; p + 3 * kThreads < p1; p += 4 * kThreads) {  // 8 independent loads in flight per lane
+        int64_t t[4];
+        int a[4], b[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) t[u] = seg_pair_to_frame(st, p + u * kThreads);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { a[u] = labels[t[u]]; b[u] = labels[t[u] + lag]; }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) bin_pair(a[u], b[u], t[u]);
+    }
+    for (; p < p1; p += kThreads) {
+        const int64_t t = seg_pair_to_frame(st, p);
+        bin_pair(labels[t], labels[t + lag], t);
     }
     __syncthreads();
     out_t* dst = counts + (size_t)r0 * k;
@@ -68,10 +94,7 @@ __global__ __launch_bounds__(kThreads) void count_lds_kernel(
         const lds_t v = bins[i];
         if (v != (lds_t)0) atomicAdd(&dst[i], (out_t)v);
     }
-    if (pairs_out) {
-        local_pairs = wave_sum_u64(local_pairs);
-        if ((tid & 63) == 0 && local_pairs) atomicAdd(pairs_out, local_pairs);
-    }
+    if (pairs_out) block_add_u64(local_pairs, pairs_out);
 }
 
 // Very large k: no privatisation, one global atomic per pair.
@@ -93,10 +116,7 @@ __global__ __launch_bounds__(kThreads) void count_global_kernel(
             ++local_pairs;
         }
     }
-    if (pairs_out) {
-        local_pairs = wave_sum_u64(local_pairs);
-        if ((threadIdx.x & 63) == 0 && local_pairs) atomicAdd(pairs_out, local_pairs);
-    }
+    if (pairs_out) block_add_u64(local_pairs, pairs_out);
 }
 
 __global__ __launch_bounds__(kThreads) void state_counts_kernel(
@@ -146,7 +166,7 @@ CountPlan plan_counts(const msm_ctx* ctx, int k, int64_t total_pairs, size_t bin
     pl.row_blocks = msm_ceil_div(k, rows);
     pl.rows = msm_ceil_div(k, pl.row_blocks);  // balance the blocks
     pl.lds_bytes = (size_t)pl.rows * row_bytes;
-    const int wg_per_cu = pl.lds_bytes <= (size_t)kLdsBudgetSmall ? 2 : 1;
+    const int wg_per_cu = 1;  // 1024-thread workgroups
     int chunks = std::max(1, ctx->n_cu * wg_per_cu / pl.row_blocks);
     // keep at least ~2k pairs per workgroup so the LDS flush amortises
     const int64_t max_chunks = std::max<int64_t>(1, total_pairs / 2048);
@@ -243,7 +263,7 @@ msm_status msm_state_counts(msm_ctx* ctx, const int32_t* d_labels, int64_t n, in
     MSM_HIP(ctx, hipMemsetAsync(d_visits, 0, (size_t)k * sizeof(int64_t), ctx->stream));
     if (n == 0) return MSM_OK;
     const int blocks = (int)std::min<int64_t>(std::max<int64_t>(1, msm_ceil_div(n, kThreads * 16)),
-                                              (int64_t)ctx->n_cu * 4);
+                                              (int64_t)ctx->n_cu * 2);
     const size_t lds = k <= 16384 ? (size_t)k * sizeof(unsigned int) : 0;
     hipLaunchKernelGGL(state_counts_kernel, dim3(blocks), dim3(kThreads), lds, ctx->stream, d_labels, n, k,
                        (unsigned long long*)d_visits);

@@ -142,19 +142,33 @@ __global__ __launch_bounds__(kThreads) void absmax_kernel(const T* __restrict__ 
                                                          const double* __restrict__ stdv,
                                                          unsigned long long* __restrict__ out_bits) {
     double m = 0.0;
-    if (ld == d && !mean) {  // contiguous, no whitening: a flat stream, 4 loads in flight per lane
-        const int64_t total = n * d;
-        const int64_t step = (int64_t)gridDim.x * kThreads;
+    const int64_t total = n * d;
+    const int64_t step = (int64_t)gridDim.x * kThreads;
+    if (ld == d && !mean) {  // contiguous, no whitening: a flat stream of 16-byte loads, 4 in flight per lane
+        constexpr int V = 16 / (int)sizeof(T);
+        struct alignas(16) Pack { T v[V]; };
+        const bool aligned = (reinterpret_cast<uintptr_t>(x) & 15) == 0;
+        const int64_t npack = aligned ? total / V : 0;
+        const Pack* xp = reinterpret_cast<const Pack*>(x);
         int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x;
-        for (; i + 3 * step < total; i += 4 * step) {
-            const double a = fabs((double)x[i]), b = fabs((double)x[i + step]);
-            const double c = fabs((double)x[i + 2 * step]), e = fabs((double)x[i + 3 * step]);
-            m = fmax(m, fmax(fmax(a, b), fmax(c, e)));  // fmax drops NaN operands
+        for (; i + 3 * step < npack; i += 4 * step) {
+            Pack q[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) q[u] = xp[i + u * step];
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int j = 0; j < V; ++j) m = fmax(m, fabs((double)q[u].v[j]));  // fmax drops NaN operands
         }
-        for (; i < total; i += step) m = fmax(m, fabs((double)x[i]));
+        for (; i < npack; i += step) {
+            const Pack q = xp[i];
+#pragma unroll
+            for (int j = 0; j < V; ++j) m = fmax(m, fabs((double)q.v[j]));
+        }
+        for (int64_t e = npack * V + (int64_t)blockIdx.x * kThreads + threadIdx.x; e < total; e += step)
+            m = fmax(m, fabs((double)x[e]));
     } else {
-        const int64_t total = n * d;
-        for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < total; i += (int64_t)gridDim.x * kThreads) {
+        for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < total; i += step) {
             const int64_t r = i / d;
             const int f = (int)(i - r * d);
             double v = (double)x[r * ld + f];
@@ -163,8 +177,17 @@ __global__ __launch_bounds__(kThreads) void absmax_kernel(const T* __restrict__ 
         }
     }
     for (int off = 32; off > 0; off >>= 1) m = fmax(m, __shfl_down(m, off, 64));
-    // non-negative doubles order like their bit patterns
-    if ((threadIdx.x & 63) == 0) atomicMax(out_bits, (unsigned long long)__double_as_longlong(m));
+    // one atomic per workgroup, and only when it can raise the running maximum: thousands of
+    // same-address atomics would otherwise serialise in L2 and dominate the pass.
+    // Non-negative doubles order like their bit patterns.
+    __shared__ double wave_max[kThreads / 64];
+    if ((threadIdx.x & 63) == 0) wave_max[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < kThreads / 64; ++w) m = fmax(m, wave_max[w]);
+        const unsigned long long bits = (unsigned long long)__double_as_longlong(m);
+        if (bits > __atomic_load_n(out_bits, __ATOMIC_RELAXED)) atomicMax(out_bits, bits);
+    }
 }
 
 __global__ void fit_scale_kernel(const unsigned long long* __restrict__ absmax_bits, double n_total, double tol2,
@@ -428,22 +451,33 @@ msm_status dispatch_accum(msm_ctx* ctx, const T* x, int64_t n, int d, int64_t ld
 //
 // fp64 VALU instructions and fp64 MFMAs do NOT overlap on gfx950 (tools/probe/
 // kmeans_loop_probe.hip: time = MFMA time + VALU time at any interleaving), so the
-// per-tile epilogue is kept minimal: per 16 x 16 tile and lane only max-of-4, one compare and
-// the winning TILE id; the winner inside that tile (first maximum, ascending centre index) is
-// recovered once per frame group by re-evaluating the four candidates with the same FMA chain.
+// per-tile epilogue is kept minimal: every accumulator slot (lane, r) tracks its own running
+// maximum and the tile it came from -- one fp64 compare plus three 32-bit selects (which do
+// overlap the matrix pipe), sixteen independent chains per wave, no arithmetic.  The winner of a
+// frame is then picked once per frame group from its 16 slot maxima (4 per lane, 4 lanes).
 // ---------------------------------------------------------------------------
 typedef double v4f64 __attribute__((ext_vector_type(4)));
 // 8 waves share one LDS centre tile (+ the fixed-point accumulators): two waves per SIMD even
 // when tile + accumulators take ~100 KB.
 constexpr int kMT = 512;
 
-// one v_max_f64: fmax() would first canonicalise both operands (two more fp64 VALU ops each,
-// and fp64 VALU time adds to fp64 MFMA time on this chip); NaNs lose against numbers here too
-__device__ __forceinline__ double max_f64(double a, double b) {
-    double r;
-    asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
-    return r;
-}
+// Diagnostic build only (tools/probe/kmeans_stamp_probe.hip): per-phase cycle stamps of wave 0.
+#ifdef MSM_KM_STAMPS
+__device__ unsigned long long g_km_stamps[8];
+#define KSTAMP(i)                                                                          \
+    do {                                                                                   \
+        unsigned long long t__;                                                            \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t__)::"memory");       \
+        kacc__[i] += t__ - klast__;                                                        \
+        klast__ = t__;                                                                     \
+    } while (0)
+#define KSTAMP_INIT unsigned long long kacc__[8] = {0, 0, 0, 0, 0, 0, 0, 0}; unsigned long long klast__; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(klast__)::"memory");
+#define KSTAMP_FLUSH if (threadIdx.x == 0) { for (int i__ = 0; i__ < 8; ++i__) atomicAdd(&g_km_stamps[i__], kacc__[i__]); }
+#else
+#define KSTAMP(i)
+#define KSTAMP_INIT
+#define KSTAMP_FLUSH
+#endif
 
 template <typename T, int KS, int NF, bool ACCUM, bool FOLD>
 __global__ __launch_bounds__(kMT, 2) void kmeans_mfma_kernel(
@@ -503,10 +537,30 @@ __global__ __launch_bounds__(kMT, 2) void kmeans_mfma_kernel(
         __syncthreads();
     };
     const bool single_tile = k <= tile_k;  // the usual case: the tile is staged once per workgroup
+    KSTAMP_INIT
     if (single_tile) stage_tile(0, k, (k + 15) & ~15);
-    // all waves of a block walk the centre tiles together (shared LDS tile), each on its own frames
-    for (int64_t unit0 = (int64_t)blockIdx.x * waves_per_block; unit0 < n_units;
-         unit0 += (int64_t)gridDim.x * waves_per_block) {
+    KSTAMP(0);
+    // all waves of a block walk the centre tiles together (shared LDS tile), each on its own frames.
+    // The raw coordinates of the NEXT frame group are requested before the tile loop of the
+    // current one (clamped addresses, no branches): every wave of a block reaches its loads at the
+    // same moment, so without the prefetch the whole CU would sit out each HBM round trip.
+    T raw[NF][KS];
+    auto fetch = [&](int64_t unit) {
+#pragma unroll
+        for (int u = 0; u < NF; ++u) {
+            int64_t t = unit * frames_per_wave + 16 * u + j16;
+            t = t < n ? t : n - 1;
+            const T* row = x + t * ld;
+#pragma unroll
+            for (int s = 0; s < KS; ++s) {
+                const int f = 4 * s + g;
+                raw[u][s] = row[f < d ? f : d - 1];
+            }
+        }
+    };
+    const int64_t unit_stride = (int64_t)gridDim.x * waves_per_block;
+    fetch((int64_t)blockIdx.x * waves_per_block + (tid >> 6));
+    for (int64_t unit0 = (int64_t)blockIdx.x * waves_per_block; unit0 < n_units; unit0 += unit_stride) {
         const int64_t unit = unit0 + (tid >> 6);
         double zb[NF][KS];
         int64_t fidx[NF];
@@ -515,23 +569,26 @@ __global__ __launch_bounds__(kMT, 2) void kmeans_mfma_kernel(
         for (int u = 0; u < NF; ++u) {
             fidx[u] = unit * frames_per_wave + 16 * u + j16;
             fok[u] = unit < n_units && fidx[u] < n;
-            const T* row = x + (fok[u] ? fidx[u] : 0) * ld;
 #pragma unroll
             for (int s = 0; s < KS; ++s) {
                 const int f = 4 * s + g;
-                double v = 0.0;
-                if (fok[u] && f < d) {
-                    v = load_as_f64(row + f);
-                    if (mean) v = (v - mean[f]) / stdv[f];
-                }
+                double v = (double)raw[u][s];
+                if (mean) v = (v - mean[f < d ? f : d - 1]) / stdv[f < d ? f : d - 1];
+                if (!(fok[u] && f < d)) v = 0.0;
                 if (fold && s == fold_s && g == fold_g) v = 1.0;
                 zb[u][s] = v;
             }
         }
-        double bestm[NF];
-        int btile[NF];  // winning tile as a global centre offset (k0 + 16 jt)
+        fetch(unit + unit_stride);
+        KSTAMP(1);
+        // running maximum PER ACCUMULATOR SLOT (centre k0 + 16 jt + g + 4r for slot r): one fp64
+        // compare and three 32-bit selects per slot and tile, all independent of one another
+        double bestm[NF][4];
+        int btile[NF][4];  // tile of the slot's maximum as a global centre offset (k0 + 16 jt)
 #pragma unroll
-        for (int u = 0; u < NF; ++u) { bestm[u] = -__builtin_inf(); btile[u] = 0; }
+        for (int u = 0; u < NF; ++u)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { bestm[u][r] = -__builtin_inf(); btile[u][r] = 0; }
 
         for (int k0 = 0; k0 < k; k0 += tile_k) {
             const int kt = min(tile_k, k - k0);
@@ -554,8 +611,6 @@ __global__ __launch_bounds__(kMT, 2) void kmeans_mfma_kernel(
 #pragma unroll
                     for (int r = 0; r < 4; ++r) ch[r] = chalf[jt * 16 + g + 4 * r];
                 }
-                // all MFMAs of the tile first (independent chains interleaved), then the VALU:
-                // the first group's results are complete by the time its arg-max starts
                 v4f64 acc[NF];
 #pragma unroll
                 for (int u = 0; u < NF; ++u) acc[u] = (v4f64){0.0, 0.0, 0.0, 0.0};
@@ -564,97 +619,49 @@ __global__ __launch_bounds__(kMT, 2) void kmeans_mfma_kernel(
 #pragma unroll
                     for (int u = 0; u < NF; ++u)
                         acc[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[s], zb[u][s], acc[u], 0, 0, 0);
-                // MFMA -> VALU read needs 18 wait states; hipcc pads for its own instructions
-                // but not for the inline-asm v_max_f64 below
-                __builtin_amdgcn_sched_barrier(0);
-                asm volatile("s_nop 15\n\ts_nop 3" ::: "memory");
-                __builtin_amdgcn_sched_barrier(0);
+                const int tile_c = k0 + jt * 16;
 #pragma unroll
-                for (int u = 0; u < NF; ++u) {
-                    double m0 = acc[u][0], m1 = acc[u][1], m2 = acc[u][2], m3 = acc[u][3];
-                    if constexpr (!fold) { m0 -= ch[0]; m1 -= ch[1]; m2 -= ch[2]; m3 -= ch[3]; }
-                    const double m = max_f64(max_f64(m0, m1), max_f64(m2, m3));
-                    if (m > bestm[u]) { bestm[u] = m; btile[u] = k0 + jt * 16; }
-                }
+                for (int u = 0; u < NF; ++u)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        double m = acc[u][r];
+                        if constexpr (!fold) m -= ch[r];
+                        const bool better = m > bestm[u][r];  // strict: the first (lowest) tile keeps ties
+                        bestm[u][r] = better ? m : bestm[u][r];
+                        btile[u][r] = better ? tile_c : btile[u][r];
+                    }
 #pragma unroll
                 for (int s = 0; s < KS; ++s) af[s] = af_next[s];
             }
         }
-        // Recover the winner inside the winning tile: first maximum over r (ascending centre
-        // index), re-evaluated with the oracle's chain from the centre table (L2-resident).
+        KSTAMP(2);
+        // first maximum over the lane's four slots (ties -> lowest centre index); padding centres
+        // carry -inf and lose against any real centre
+        double bm[NF];
         int bidx[NF];
-        double mr[NF][4], hr[NF][4];
-#pragma unroll
-        for (int u = 0; u < NF; ++u)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) { mr[u][r] = 0.0; hr[u][r] = 0.0; }
-        if (single_tile) {
-            // candidates and their half-norms are still in the LDS tile; the frame's coordinates
-            // are gathered from the four lanes that hold them.  All NF x 4 chains advance together:
-            // a lone dependent fp64 FMA costs ~44 cycles, sixteen independent ones pipeline.
-            const double* cj[NF];
-#pragma unroll
-            for (int u = 0; u < NF; ++u) cj[u] = cs + (btile[u] >> 4) * TS + g;  // + 4r + s*64 + g'*16
-#pragma unroll
-            for (int s = 0; s < KS; ++s)
-#pragma unroll
-                for (int gp = 0; gp < 4; ++gp) {
-                    double v[NF];
-#pragma unroll
-                    for (int u = 0; u < NF; ++u) v[u] = __shfl(zb[u][s], j16 + 16 * gp, 64);
-                    if (4 * s + gp < d) {  // skips zero padding and the folded slot
-#pragma unroll
-                        for (int u = 0; u < NF; ++u) {
-                            const double* cf = cj[u] + s * 64 + gp * 16;
-#pragma unroll
-                            for (int r = 0; r < 4; ++r) mr[u][r] = fma(v[u], cf[4 * r], mr[u][r]);
-                        }
-                    }
-                }
-#pragma unroll
-            for (int u = 0; u < NF; ++u)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) hr[u][r] = 2.0 * chalf[btile[u] + g + 4 * r];  // +inf for padding
-        } else {
-#pragma unroll
-            for (int u = 0; u < NF; ++u) {
-                const T* row = x + (fok[u] ? fidx[u] : 0) * ld;
-                for (int f = 0; f < d; ++f) {
-                    double v = load_as_f64(row + f);
-                    if (mean) v = (v - mean[f]) / stdv[f];
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int c = min(btile[u] + g + 4 * r, k - 1);
-                        const double cf = centers[(size_t)c * d + f];
-                        mr[u][r] = fma(v, cf, mr[u][r]);
-                        hr[u][r] = fma(cf, cf, hr[u][r]);
-                    }
-                }
-            }
-        }
 #pragma unroll
         for (int u = 0; u < NF; ++u) {
-            double bm = -__builtin_inf();
-            int bi = btile[u] + g;
+            bm[u] = bestm[u][0];
+            bidx[u] = btile[u][0] + g;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int c = btile[u] + g + 4 * r;
-                const double m = c < k ? mr[u][r] - 0.5 * hr[u][r] : -__builtin_inf();
-                if (m > bm) { bm = m; bi = c; }
+            for (int r = 1; r < 4; ++r) {
+                const int c = btile[u][r] + g + 4 * r;
+                const double m = bestm[u][r];
+                if (m > bm[u] || (m == bm[u] && c < bidx[u])) { bm[u] = m; bidx[u] = c; }
             }
-            bestm[u] = bm;
-            bidx[u] = bi;
         }
         // merge the 4 candidates of each frame (lanes j16, j16+16, j16+32, j16+48)
 #pragma unroll
         for (int u = 0; u < NF; ++u) {
 #pragma unroll
             for (int off = 16; off < 64; off <<= 1) {
-                const double ob = __shfl_xor(bestm[u], off, 64);
+                const double ob = __shfl_xor(bm[u], off, 64);
                 const int oi = __shfl_xor(bidx[u], off, 64);
-                if (ob > bestm[u] || (ob == bestm[u] && oi < bidx[u])) { bestm[u] = ob; bidx[u] = oi; }
+                if (ob > bm[u] || (ob == bm[u] && oi < bidx[u])) { bm[u] = ob; bidx[u] = oi; }
             }
+            if (bidx[u] >= k) bidx[u] = 0;  // only when every score is NaN / -inf
         }
+        KSTAMP(3);
 #pragma unroll
         for (int u = 0; u < NF; ++u) {
             if (!fok[u]) continue;
@@ -677,22 +684,27 @@ __global__ __launch_bounds__(kMT, 2) void kmeans_mfma_kernel(
                             if (mean) v = (v - mean[f]) / stdv[f];
                             zsq = fma(v, v, zsq);
                         }
-                        const double md = -2.0 * bestm[u] + zsq;  // -2 m == fma(-2, dot, |c|^2) exactly
+                        const double md = -2.0 * bm[u] + zsq;  // -2 m == fma(-2, dot, |c|^2) exactly
                         mindist[fidx[u]] = md > 0.0 ? md : 0.0;
                     }
                 }
             }
         }
+        KSTAMP(4);
     }
+    KSTAMP(7);
     if constexpr (ACCUM) {
         if (lds_acc) {
             __syncthreads();
+            KSTAMP(5);
             for (int i = tid; i < k * d; i += kMT)
                 if (lsum[i]) atomicAdd(&sums[i], lsum[i]);
             for (int i = tid; i < k; i += kMT)
                 if (lcnt[i]) atomicAdd(&counts[i], lcnt[i]);
         }
     }
+    KSTAMP(6);
+    KSTAMP_FLUSH
 }
 
 template <typename T, int KS, bool ACCUM>

@@ -221,19 +221,34 @@ __global__ __launch_bounds__(kThreads) void project_kernel(
 // load per q.  Every 256-byte row is consumed whole across the four q loads.
 // ---------------------------------------------------------------------------
 typedef double v4f64 __attribute__((ext_vector_type(4)));
-constexpr int kPChunk = 64;  // features per register-resident chunk of W'
+constexpr int kPChunk = 64;  // features per pipelined chunk (4 x 16-byte loads per lane)
 
+// W' (zero-padded to 16 columns, row stride 16) and mu live in LDS: the A operand of every MFMA
+// is one ds_read_b64, which keeps the kernel at <= 128 VGPRs (4 waves per SIMD) for any F.
+// VEC path: the raw 16-byte loads of the NEXT (frame group, chunk) are issued before the MFMAs
+// of the current one, so HBM latency overlaps the matrix work inside a wave as well.
 template <typename T, bool VEC>
 __global__ __launch_bounds__(kThreads) void project_mfma_kernel(
     const T* __restrict__ x, int64_t n, int F, int64_t ld, const double* __restrict__ mu,
     const double* __restrict__ inv_sigma, const double* __restrict__ m2, const double* __restrict__ W, int d,
     int64_t ldw, double* __restrict__ y, int64_t ldy) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char proj_smem[];
+    double* wl = reinterpret_cast<double*>(proj_smem);  // [F16][16]
+    const int F16 = (F + 15) & ~15;
+    double* mul = wl + (size_t)F16 * 16;  // [F16]
+    for (int idx = threadIdx.x; idx < F16 * 16; idx += kThreads) {
+        const int f = idx >> 4, c = idx & 15;
+        wl[idx] = (f < F && c < d) ? inv_sigma[f] * W[(size_t)f * ldw + c] : 0.0;
+    }
+    for (int f = threadIdx.x; f < F16; f += kThreads) mul[f] = f < F ? mu[f] : 0.0;
+    __syncthreads();
+
     const int lane = threadIdx.x & 63;
     const int j = lane & 15, g = lane >> 4;
     const int64_t wave_id = ((int64_t)blockIdx.x * kThreads + threadIdx.x) >> 6;
     const int64_t n_waves = ((int64_t)gridDim.x * kThreads) >> 6;
     const int64_t n_groups = (n + 15) / 16;
-    const int n_chunks = (F + kPChunk - 1) / kPChunk;
+    const int n_chunks = (F16 + kPChunk - 1) / kPChunk;
 
     // accumulator start: -(m2 . W[:, c]) for this lane's 4 output columns c = g + 4r
     v4f64 acc0 = {0.0, 0.0, 0.0, 0.0};
@@ -247,57 +262,92 @@ __global__ __launch_bounds__(kThreads) void project_mfma_kernel(
             acc0[r] = -a;
         }
     }
-    double wa[16], muv[16];
-    auto load_w = [&](int f0) {
-#pragma unroll
-        for (int s = 0; s < 16; ++s) {
-            const int f = f0 + 16 * (s >> 2) + 4 * g + (s & 3);
-            const bool ok = f < F && j < d;
-            wa[s] = ok ? inv_sigma[f] * W[(size_t)f * ldw + j] : 0.0;
-            muv[s] = f < F ? mu[f] : 0.0;
-        }
-    };
-    if (n_chunks == 1) load_w(0);
-
-    for (int64_t grp = wave_id; grp < n_groups; grp += n_waves) {
+    auto store = [&](int64_t grp, const v4f64& acc) {
         const int64_t t = grp * 16 + j;
-        const bool tok = t < n;
-        const T* row = x + (tok ? t : 0) * ld;
-        v4f64 acc = acc0;
-        for (int ch = 0; ch < n_chunks; ++ch) {
-            const int f0 = ch * kPChunk;
-            if (n_chunks > 1) load_w(f0);
-            double zv[16];
-            if constexpr (VEC) {
-                using VT = T __attribute__((ext_vector_type(4)));
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const int f = f0 + 16 * q + 4 * g;
-                    VT v = {(T)0, (T)0, (T)0, (T)0};
-                    if (tok && f < F) v = *reinterpret_cast<const VT*>(row + f);
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) zv[4 * q + i] = (double)v[i];
-                }
-            } else {
-#pragma unroll
-                for (int s = 0; s < 16; ++s) {
-                    const int f = f0 + 16 * (s >> 2) + 4 * g + (s & 3);
-                    zv[s] = (tok && f < F) ? (double)row[f] : 0.0;
-                }
-            }
-#pragma unroll
-            for (int s = 0; s < 16; ++s) {
-                double z = zv[s] - muv[s];
-                if (!(zv[s] == zv[s]) || !tok) z = 0.0;
-                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(wa[s], z, acc, 0, 0, 0);
-            }
-        }
-        if (tok) {
+        if (t < n) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int c = g + 4 * r;
                 if (c < d) y[t * ldy + c] = acc[r];
             }
+        }
+    };
+
+    if constexpr (VEC) {
+        using VT = T __attribute__((ext_vector_type(4)));
+        // feature offsets past the end (F16 not a multiple of 64) are clamped onto valid memory;
+        // their W' rows are read as the zero rows of a clamped LDS index instead
+        auto load_raw = [&](int64_t grp, int ch, VT (&raw)[4]) {
+            int64_t t = grp * 16 + j;
+            t = t < n ? t : n - 1;
+            const T* row = x + t * ld;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                int f = ch * kPChunk + 16 * q + 4 * g;
+                f = f < F16 ? f : F16 - 4;
+                raw[q] = *reinterpret_cast<const VT*>(row + f);
+            }
+        };
+        int64_t grp = wave_id;
+        int ch = 0;
+        VT cur[4];
+        if (grp < n_groups) load_raw(grp, 0, cur);
+        v4f64 acc = acc0;
+        while (grp < n_groups) {
+            int64_t ngrp = grp;
+            int nch = ch + 1;
+            if (nch == n_chunks) { nch = 0; ngrp = grp + n_waves; }
+            VT nxt[4];
+            if (ngrp < n_groups) load_raw(ngrp, nch, nxt);
+            else {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) nxt[q] = cur[q];
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int fq = ch * kPChunk + 16 * q + 4 * g;
+                const bool live = fq < F16;
+                const int fb = live ? fq : 0;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const double xv = (double)cur[q][i];
+                    double z = xv - mul[fb + i];
+                    if (!(xv == xv)) z = 0.0;
+                    const double w = live ? wl[(fb + i) * 16 + j] : 0.0;
+                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(w, z, acc, 0, 0, 0);
+                }
+            }
+            if (nch == 0) {
+                store(grp, acc);
+                acc = acc0;
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) cur[q] = nxt[q];
+            grp = ngrp;
+            ch = nch;
+        }
+    } else {
+        for (int64_t grp = wave_id; grp < n_groups; grp += n_waves) {
+            const int64_t t = grp * 16 + j;
+            const bool tok = t < n;
+            const T* row = x + (tok ? t : 0) * ld;
+            v4f64 acc = acc0;
+            for (int f0 = 0; f0 < F16; f0 += 16) {
+                double zv[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int f = f0 + 4 * g + i;
+                    zv[i] = (tok && f < F) ? (double)row[f] : 0.0;
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int f = f0 + 4 * g + i;
+                    double z = zv[i] - mul[f];
+                    if (!(zv[i] == zv[i]) || !tok || f >= F) z = 0.0;
+                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(wl[f * 16 + j], z, acc, 0, 0, 0);
+                }
+            }
+            store(grp, acc);
         }
     }
 }
@@ -390,13 +440,15 @@ msm_status msm_project(msm_ctx* ctx, const void* d_x, msm_dtype dtype, int64_t n
     MSM_REQUIRE(ctx, dtype == MSM_F32 || dtype == MSM_F64, "msm_project: bad dtype");
     if (n == 0) return MSM_OK;
     MSM_REQUIRE(ctx, d_x && d_mu && d_inv_sigma && d_w && d_y, "msm_project: NULL pointer");
-    if (d <= 16) {
+    if (d <= 16 && (size_t)((F + 15) & ~15) * 17 * sizeof(double) <= 48 * 1024) {
         const int64_t n_groups = (n + 15) / 16;
         const int grid = (int)std::min<int64_t>((n_groups + 3) / 4, (int64_t)ctx->n_cu * 8);
         const size_t esz = dtype == MSM_F32 ? 4 : 8;
+        const int F16 = (F + 15) & ~15;
+        const size_t plds = (size_t)F16 * 17 * sizeof(double);
         const bool vec = (F % 16 == 0) && (ld % 4 == 0) && (((uintptr_t)d_x) % (4 * esz) == 0);
 #define MSM_PROJ(T, V)                                                                                         \
-        hipLaunchKernelGGL((project_mfma_kernel<T, V>), dim3(grid), dim3(kThreads), 0, ctx->stream, (const T*)d_x, n, \
+        hipLaunchKernelGGL((project_mfma_kernel<T, V>), dim3(grid), dim3(kThreads), plds, ctx->stream, (const T*)d_x, n, \
                            F, ld, d_mu, d_inv_sigma, d_mean2, d_w, d, ldw, d_y, ldy)
         if (dtype == MSM_F32) { if (vec) MSM_PROJ(float, true); else MSM_PROJ(float, false); }
         else { if (vec) MSM_PROJ(double, true); else MSM_PROJ(double, false); }

@@ -1,0 +1,38 @@
+// Diagnostic: where does the k-means accumulate kernel spend its cycles?  (wave 0 of every block)
+#define MSM_KM_STAMPS 1
+#include "../../pmarlo_amd/csrc/kmeans.hip"
+#include "../../pmarlo_amd/csrc/ctx.hip"
+#include <vector>
+#include <cstdio>
+#include <cmath>
+int main() {
+    const int64_t n = 1000000; const int d = 10, k = 500;
+    msm_ctx* ctx; if (msm_ctx_create(0, nullptr, &ctx)) return 1;
+    std::vector<double> Y(n * d);
+    unsigned long long sd = 12345;
+    for (auto& v : Y) { sd = sd * 6364136223846793005ull + 1442695040888963407ull; v = ((sd >> 11) * (1.0 / 9007199254740992.0) - 0.5) * 4.0; }
+    double *dY, *dC, *dS; int64_t *dsum, *dcnt;
+    hipMalloc(&dY, n * d * 8); hipMalloc(&dC, k * d * 8); hipMalloc(&dS, 64); hipMalloc(&dsum, k * d * 8); hipMalloc(&dcnt, k * 8);
+    hipMemcpy(dY, Y.data(), n * d * 8, hipMemcpyHostToDevice);
+    if (msm_kmeans_fit_begin(ctx, dY, MSM_F64, n, d, d, nullptr, nullptr, k, 7, 1, (double)n, 0.0, dC, dS)) { printf("%s\n", msm_last_error(ctx)); return 1; }
+    hipMemset(dsum, 0, k * d * 8); hipMemset(dcnt, 0, k * 8);
+    unsigned long long z[8] = {0};
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    float ms = 0;
+    for (int rep = 0; rep < 3; ++rep) {
+        hipMemcpyToSymbol(HIP_SYMBOL(g_km_stamps), z, sizeof(z));
+        hipEventRecord(e0, ctx->stream);
+        msm_kmeans_accumulate(ctx, dY, MSM_F64, n, d, d, dC, k, nullptr, nullptr, dS, dsum, dcnt);
+        hipEventRecord(e1, ctx->stream);
+        msm_sync(ctx);
+        hipEventElapsedTime(&ms, e0, e1);
+    }
+    unsigned long long st[8];
+    hipMemcpyFromSymbol(st, HIP_SYMBOL(g_km_stamps), sizeof(st));
+    const char* names[] = {"stage centres", "convert + prefetch issue", "tile loop", "select + merge", "accumulate (LDS atomics)", "barrier before flush", "flush", "loop exit"};
+    unsigned long long tot = 0; for (int i = 0; i < 8; ++i) tot += st[i];
+    printf("kernel %.3f ms; stamps are sums over %d blocks (wave 0)\n", ms, 256);
+    for (int i = 0; i < 8; ++i) printf("%-28s %12llu ticks  %5.1f%%  per block %.0f\n", names[i], st[i], 100.0 * st[i] / tot, st[i] / 256.0);
+    printf("total per block %.0f ticks -> %.3f ms kernel => tick rate %.1f MHz\n", tot / 256.0, ms, tot / 256.0 / ms / 1e3);
+    return 0;
+}
