@@ -451,15 +451,22 @@ msm_status dispatch_accum(msm_ctx* ctx, const T* x, int64_t n, int d, int64_t ld
 //
 // fp64 VALU instructions and fp64 MFMAs do NOT overlap on gfx950 (tools/probe/
 // kmeans_loop_probe.hip: time = MFMA time + VALU time at any interleaving), so the
-// per-tile epilogue is kept minimal: every accumulator slot (lane, r) tracks its own running
-// maximum and the tile it came from -- one fp64 compare plus three 32-bit selects (which do
-// overlap the matrix pipe), sixteen independent chains per wave, no arithmetic.  The winner of a
-// frame is then picked once per frame group from its 16 slot maxima (4 per lane, 4 lanes).
+// per-tile epilogue is kept minimal (see the tile loop): a max tree, one compare and the id of
+// the winning tile PAIR; the winner inside that pair is recovered once per frame group by
+// re-scoring its candidates with the same FMA chain from the LDS tile.
 // ---------------------------------------------------------------------------
 typedef double v4f64 __attribute__((ext_vector_type(4)));
 // 8 waves share one LDS centre tile (+ the fixed-point accumulators): two waves per SIMD even
 // when tile + accumulators take ~100 KB.
 constexpr int kMT = 512;
+
+// one v_max_f64: fmax() would first canonicalise both operands (two more VALU ops each);
+// NaNs lose against numbers here too.  The caller pads the MFMA -> VALU hazard itself.
+__device__ __forceinline__ double max_f64(double a, double b) {
+    double r;
+    asm volatile("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
 
 // Diagnostic build only (tools/probe/kmeans_stamp_probe.hip): per-phase cycle stamps of wave 0.
 #ifdef MSM_KM_STAMPS
@@ -537,8 +544,11 @@ __global__ __launch_bounds__(kMT, 2) void kmeans_mfma_kernel(
         __syncthreads();
     };
     const bool single_tile = k <= tile_k;  // the usual case: the tile is staged once per workgroup
+    __shared__ int unit_ctr;
     KSTAMP_INIT
+    if (tid == 0) unit_ctr = kMT / 64;  // groups 0 .. waves-1 of the block's range are taken statically
     if (single_tile) stage_tile(0, k, (k + 15) & ~15);
+    else __syncthreads();
     KSTAMP(0);
     // all waves of a block walk the centre tiles together (shared LDS tile), each on its own frames.
     // The raw coordinates of the NEXT frame group are requested before the tile loop of the
@@ -558,10 +568,30 @@ __global__ __launch_bounds__(kMT, 2) void kmeans_mfma_kernel(
             }
         }
     };
+    // Frame groups are handed out dynamically inside a workgroup (single-tile case): the two waves
+    // of a SIMD do not progress at the same rate (oldest-first arbitration), and with a static
+    // split the favoured waves idle at the final barrier for ~15% of the kernel.  Each workgroup
+    // owns a contiguous range of groups; a wave takes the next one from an LDS counter and
+    // prefetches it.  The multi-tile case keeps the static stride (it needs block-wide barriers).
+    const int wave = tid >> 6;
     const int64_t unit_stride = (int64_t)gridDim.x * waves_per_block;
-    fetch((int64_t)blockIdx.x * waves_per_block + (tid >> 6));
-    for (int64_t unit0 = (int64_t)blockIdx.x * waves_per_block; unit0 < n_units; unit0 += unit_stride) {
-        const int64_t unit = unit0 + (tid >> 6);
+    const int64_t units_per_block = (n_units + gridDim.x - 1) / gridDim.x;
+    const int64_t u_begin = single_tile ? (int64_t)blockIdx.x * units_per_block : 0;
+    const int64_t u_end = single_tile ? min(n_units, u_begin + units_per_block) : n_units;
+    int64_t cur = single_tile ? u_begin + wave : (int64_t)blockIdx.x * waves_per_block + wave;
+    fetch(cur);
+    for (;;) {
+        // static mode: the exit test is block-uniform (every wave takes part in the barriers)
+        if (single_tile ? cur >= u_end : cur - wave >= n_units) break;
+        const int64_t unit = cur;
+        int64_t nxt;
+        if (single_tile) {
+            int t = 0;
+            if (lane == 0) t = atomicAdd(&unit_ctr, 1);
+            nxt = u_begin + __builtin_amdgcn_readfirstlane(t);
+        } else {
+            nxt = cur + unit_stride;
+        }
         double zb[NF][KS];
         int64_t fidx[NF];
         bool fok[NF];
@@ -579,87 +609,126 @@ __global__ __launch_bounds__(kMT, 2) void kmeans_mfma_kernel(
                 zb[u][s] = v;
             }
         }
-        fetch(unit + unit_stride);
+        fetch(nxt);
+        cur = nxt;
         KSTAMP(1);
-        // running maximum PER ACCUMULATOR SLOT (centre k0 + 16 jt + g + 4r for slot r): one fp64
-        // compare and three 32-bit selects per slot and tile, all independent of one another
-        double bestm[NF][4];
-        int btile[NF][4];  // tile of the slot's maximum as a global centre offset (k0 + 16 jt)
+        // Final winner of every frame group: score (replicated on the frame's 4 lanes) and index.
+        double bm[NF];
+        int bidx[NF];
 #pragma unroll
-        for (int u = 0; u < NF; ++u)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) { bestm[u][r] = -__builtin_inf(); btile[u][r] = 0; }
+        for (int u = 0; u < NF; ++u) { bm[u] = -__builtin_inf(); bidx[u] = 0; }
 
         for (int k0 = 0; k0 < k; k0 += tile_k) {
             const int kt = min(tile_k, k - k0);
             const int kt16 = (kt + 15) & ~15;
             if (!single_tile) {
-                __syncthreads();  // previous tile fully consumed
+                __syncthreads();  // previous chunk fully consumed (its recovery included)
                 stage_tile(k0, kt, kt16);
             }
             const int n_tiles = kt16 / 16;
-            double af[KS], af_next[KS];
+            // ---- tile loop, two 16-centre tiles per trip.  Per lane and frame group only the
+            // running maximum over everything seen so far and the PAIR it came from are kept:
+            // 22 VALU instructions per pair of wave-tiles (every VALU issue costs matrix-pipe time
+            // on this chip, tools/probe/valu_mix_probe.hip), no arithmetic on the scores.
+            double best[NF];
+            int bpair[NF];
 #pragma unroll
-            for (int s = 0; s < KS; ++s) af[s] = cs[s * 64 + lane];
-            for (int jt = 0; jt < n_tiles; ++jt) {
-                // next tile's A fragment is fetched under this tile's MFMAs (clamped on the last)
-                const int jn = min(jt + 1, n_tiles - 1);
+            for (int u = 0; u < NF; ++u) { best[u] = -__builtin_inf(); bpair[u] = 0; }
+            for (int jt = 0; jt < n_tiles; jt += 2) {
+                const int jb = min(jt + 1, n_tiles - 1);  // odd tile count: the last tile twice
+                double afa[KS], afb[KS];
 #pragma unroll
-                for (int s = 0; s < KS; ++s) af_next[s] = cs[jn * TS + s * 64 + lane];
-                double ch[4] = {0.0, 0.0, 0.0, 0.0};
-                if constexpr (!fold) {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) ch[r] = chalf[jt * 16 + g + 4 * r];
+                for (int s = 0; s < KS; ++s) {
+                    afa[s] = cs[jt * TS + s * 64 + lane];
+                    afb[s] = cs[jb * TS + s * 64 + lane];
                 }
-                v4f64 acc[NF];
+                v4f64 acca[NF], accb[NF];
 #pragma unroll
-                for (int u = 0; u < NF; ++u) acc[u] = (v4f64){0.0, 0.0, 0.0, 0.0};
+                for (int u = 0; u < NF; ++u) { acca[u] = (v4f64){0.0, 0.0, 0.0, 0.0}; accb[u] = acca[u]; }
 #pragma unroll
                 for (int s = 0; s < KS; ++s)
 #pragma unroll
                     for (int u = 0; u < NF; ++u)
-                        acc[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[s], zb[u][s], acc[u], 0, 0, 0);
-                const int tile_c = k0 + jt * 16;
+                        acca[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(afa[s], zb[u][s], acca[u], 0, 0, 0);
 #pragma unroll
-                for (int u = 0; u < NF; ++u)
+                for (int s = 0; s < KS; ++s)
+#pragma unroll
+                    for (int u = 0; u < NF; ++u)
+                        accb[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(afb[s], zb[u][s], accb[u], 0, 0, 0);
+                if constexpr (!fold) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        double m = acc[u][r];
-                        if constexpr (!fold) m -= ch[r];
-                        const bool better = m > bestm[u][r];  // strict: the first (lowest) tile keeps ties
-                        bestm[u][r] = better ? m : bestm[u][r];
-                        btile[u][r] = better ? tile_c : btile[u][r];
+                        const double ha = chalf[jt * 16 + g + 4 * r], hb = chalf[jb * 16 + g + 4 * r];
+#pragma unroll
+                        for (int u = 0; u < NF; ++u) { acca[u][r] -= ha; accb[u][r] -= hb; }
                     }
+                }
+                // MFMA -> VALU read needs 18 wait states; hipcc pads for its own instructions but
+                // not for the inline-asm v_max_f64 below (tile a finished long ago, tile b has not)
+                __builtin_amdgcn_sched_barrier(0);
+                double ma[NF], mb[NF];
 #pragma unroll
-                for (int s = 0; s < KS; ++s) af[s] = af_next[s];
+                for (int u = 0; u < NF; ++u) ma[u] = max_f64(max_f64(acca[u][0], acca[u][1]), max_f64(acca[u][2], acca[u][3]));
+                asm volatile("s_nop 7" ::: "memory");
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int u = 0; u < NF; ++u) {
+                    mb[u] = max_f64(max_f64(accb[u][0], accb[u][1]), max_f64(accb[u][2], accb[u][3]));
+                    const double m = max_f64(ma[u], mb[u]);
+                    const bool better = m > best[u];  // strict: the first pair keeps ties
+                    best[u] = better ? m : best[u];
+                    bpair[u] = better ? jt : bpair[u];
+                }
             }
-        }
-        KSTAMP(2);
-        // first maximum over the lane's four slots (ties -> lowest centre index); padding centres
-        // carry -inf and lose against any real centre
-        double bm[NF];
-        int bidx[NF];
+            KSTAMP(2);
+            // ---- winner of this chunk, per frame.  M = max over the frame's 4 lanes; the lane(s)
+            // holding M name the pair; that pair's 8 candidate centres of the lane (2 tiles x 4
+            // slots) are re-scored with the SAME chain, two per lane, and the lowest index with
+            // score == M wins.  Several lanes holding M (duplicate centres, exact ties) are walked
+            // one after the other -- one extra trip of the loop per additional tied lane.
 #pragma unroll
-        for (int u = 0; u < NF; ++u) {
-            bm[u] = bestm[u][0];
-            bidx[u] = btile[u][0] + g;
+            for (int u = 0; u < NF; ++u) {
+                double M = best[u];
+                M = fmax(M, __shfl_xor(M, 16, 64));
+                M = fmax(M, __shfl_xor(M, 32, 64));
+                const unsigned long long tied = __ballot(best[u] == M) >> j16;  // bits 0,16,32,48: lanes g = 0..3
+                unsigned pending = (unsigned)(tied & 1) | (unsigned)((tied >> 15) & 2) | (unsigned)((tied >> 30) & 4) |
+                                   (unsigned)((tied >> 45) & 8);
+                int found = 0x7fffffff;
+                while (__any(pending != 0)) {
+                    const int gs = pending ? __builtin_ctz(pending) : 0;  // candidate-owning lane of this frame
+                    const int pj = __shfl(bpair[u], j16 + 16 * gs, 64);
+                    const int ta = pj, tb = min(pj + 1, n_tiles - 1);
+                    // this lane scores slot r = g of tiles ta and tb for owner gs: centre row gs + 4g
+                    const int crow = gs + 4 * g;
+                    const double* ca = cs + ta * TS + crow;
+                    const double* cb = cs + tb * TS + crow;
+                    double da = 0.0, db = 0.0;
 #pragma unroll
-            for (int r = 1; r < 4; ++r) {
-                const int c = btile[u][r] + g + 4 * r;
-                const double m = bestm[u][r];
-                if (m > bm[u] || (m == bm[u] && c < bidx[u])) { bm[u] = m; bidx[u] = c; }
+                    for (int s = 0; s < KS; ++s)
+#pragma unroll
+                        for (int gp = 0; gp < 4; ++gp) {
+                            const double zv = __shfl(zb[u][s], j16 + 16 * gp, 64);
+                            da = fma(ca[s * 64 + gp * 16], zv, da);
+                            db = fma(cb[s * 64 + gp * 16], zv, db);
+                        }
+                    if constexpr (!fold) {
+                        da -= chalf[ta * 16 + crow];
+                        db -= chalf[tb * 16 + crow];
+                    }
+                    int cand = 0x7fffffff;
+                    if (pending) {
+                        if (db == M) cand = k0 + tb * 16 + crow;
+                        if (da == M) cand = k0 + ta * 16 + crow;  // ta <= tb: the lower index last
+                    }
+                    cand = min(cand, __shfl_xor(cand, 16, 64));
+                    cand = min(cand, __shfl_xor(cand, 32, 64));
+                    found = min(found, cand);
+                    pending &= pending - 1;
+                }
+                // merge into the running winner over chunks (strict: the earlier chunk keeps ties)
+                if (M > bm[u] && found < k) { bm[u] = M; bidx[u] = found; }
             }
-        }
-        // merge the 4 candidates of each frame (lanes j16, j16+16, j16+32, j16+48)
-#pragma unroll
-        for (int u = 0; u < NF; ++u) {
-#pragma unroll
-            for (int off = 16; off < 64; off <<= 1) {
-                const double ob = __shfl_xor(bm[u], off, 64);
-                const int oi = __shfl_xor(bidx[u], off, 64);
-                if (ob > bm[u] || (ob == bm[u] && oi < bidx[u])) { bm[u] = ob; bidx[u] = oi; }
-            }
-            if (bidx[u] >= k) bidx[u] = 0;  // only when every score is NaN / -inf
         }
         KSTAMP(3);
 #pragma unroll
