@@ -37,6 +37,12 @@ constexpr int kMaxPairs = 128;  // n <= 256
 struct JacobiShared {
     double2 cs[kMaxPairs];  // (c, s) of pivot i: one 16-byte LDS read
     int p[kMaxPairs], q[kMaxPairs];
+    int colw[kMaxPairs];  // p | q << 16            (even-n fast path: one read instead of the
+    int roww[kMaxPairs];  // p * ld | (q * ld) << 16   tournament arithmetic + row multiplies)
+    // second buffer of the pipelined path (n <= 64): rotations of round r+1 are formed by wave 0
+    // while the other waves still apply round r
+    double2 cs2[2][32];
+    int colw2[2][32], roww2[2][32];
     double red[kEigThreads / 64];
     double bc[4];
     int ibc[4];
@@ -95,17 +101,16 @@ __device__ __forceinline__ void jacobi_rotation(double app, double aqq, double a
     s = t * c;
 }
 
-// Round-robin tournament: pivot i of round r pairs indices (p < q); index npad-1 is the
-// padding player when n is odd.  Pure integer arithmetic (cheaper than an LDS table: the
+// Round-robin tournament: pivot i of round r pairs indices (p, q); index npad-1 is the
+// padding player when n is odd (it only ever appears as q).  Pure integer arithmetic (cheaper than an LDS table: the
 // update phase is bound by LDS instruction issue).
+// (p, q) is NOT ordered: p = round + i and q = round - i (mod npad-1) are runs of consecutive
+// indices over i, so a wave's column accesses A[.][p_i] / A[.][q_i] fall on consecutive LDS
+// banks (ordering the pair by min/max scrambled them: bank conflicts in the update phase).
 __device__ __forceinline__ void pivot_pair(int round, int i, int npad, int& p, int& q) {
-    int a, b;
-    if (i == 0) { a = npad - 1; b = round; }
-    else {
-        a = round + i; if (a >= npad - 1) a -= npad - 1;
-        b = round - i; if (b < 0) b += npad - 1;
-    }
-    p = min(a, b); q = max(a, b);
+    if (i == 0) { p = round; q = npad - 1; return; }
+    p = round + i; if (p >= npad - 1) p -= npad - 1;
+    q = round - i; if (q < 0) q += npad - 1;
 }
 
 // A (n x n, row stride ld, symmetric) -> diagonal; V -> eigenvectors in columns.
@@ -119,8 +124,16 @@ __device__ __forceinline__ void pivot_pair(int round, int i, int npad, int& p, i
 //      disjoint 2x2 blocks (rows of pivot a, columns of pivot b) and block (a, b) needs
 //      only its own four entries and the two rotations -- no intermediate "rows done"
 //      barrier.  V <- VJ rides in the same phase.
+__device__ __forceinline__ int jacobi_eigh_pipelined(double* A, double* V, int n, int ld, JacobiShared* sh,
+                                                     int max_sweeps);
+
 __device__ __forceinline__ int jacobi_eigh(double* A, double* V, int n, int ld, JacobiShared* sh, int max_sweeps) {
     const int tid = threadIdx.x, nt = blockDim.x;
+    {
+        const int mh = n / 2;
+        if ((n & 1) == 0 && mh >= 4 && mh <= 32 && mh * mh <= nt && mh * n <= 2 * nt && n * ld < 65536 && nt >= 64)
+            return jacobi_eigh_pipelined(A, V, n, ld, sh, max_sweeps);
+    }
     for (int i = tid; i < n * n; i += nt) V[(i / n) * ld + (i % n)] = (i / n == i % n) ? 1.0 : 0.0;
     __syncthreads();
     if (n < 2) return 0;
@@ -146,6 +159,9 @@ __device__ __forceinline__ int jacobi_eigh(double* A, double* V, int n, int ld, 
         JSTAMP(1);
         // fast path: one 2x2 block and at most two V items per thread, indices fixed for the sweep
         const bool fast = (m * m <= nt) && (m * n <= 2 * nt);
+        // n even: nobody sits out, so the fast path needs no padding logic at all (n = 64 with 1024
+        // threads: every thread owns exactly one 2x2 block and two V items)
+        const bool fast_even = fast && (n & 1) == 0 && n * ld < 65536;
         const int my_ia = tid / m, my_ib = tid - my_ia * m;
         const bool has_blk = tid < m * m;
         const int v_ib0 = tid / n, v_r0 = tid - v_ib0 * n;
@@ -163,11 +179,39 @@ __device__ __forceinline__ int jacobi_eigh(double* A, double* V, int n, int ld, 
                 double c = 1.0, s = 0.0;
                 if (q < n) jacobi_rotation(A[p * ld + p], A[q * ld + q], A[p * ld + q], c, s);
                 sh->cs[i] = make_double2(c, s); sh->p[i] = p; sh->q[i] = q;
+                sh->colw[i] = p | (q << 16);
+                sh->roww[i] = (p * ld) | ((q * ld) << 16);
             }
             JSTAMP(2);
             __syncthreads();
             JSTAMP(3);
-            if (fast) {
+            if (fast_even) {
+                // ~70 instructions per thread (the phase is bound by instruction issue: 16 waves
+                // on 4 SIMDs).  All loads first, clamped indices for idle threads, stores guarded.
+                const int wr = sh->roww[my_ia_c], wc = sh->colw[my_ib_c];
+                const int w0 = sh->colw[v_ib0_c], w1 = sh->colw[v_ib1_c];
+                const double2 ra = sh->cs[my_ia_c], rb = sh->cs[my_ib_c], r0 = sh->cs[v_ib0_c], r1 = sh->cs[v_ib1_c];
+                double* Ap = A + (wr & 0xffff);
+                double* Aq = A + (wr >> 16);
+                const int pb = wc & 0xffff, qb = wc >> 16;
+                double* V0 = V + v_r0 * ld;
+                double* V1 = V + v_r1_c * ld;
+                const int vp0 = w0 & 0xffff, vq0 = w0 >> 16, vp1 = w1 & 0xffff, vq1 = w1 >> 16;
+                const double app = Ap[pb], apq = Ap[qb], aqp = Aq[pb], aqq = Aq[qb];
+                const double x0p = V0[vp0], x0q = V0[vq0], x1p = V1[vp1], x1q = V1[vq1];
+                const double rpp = fma(-ra.y, aqp, ra.x * app), rpq = fma(-ra.y, aqq, ra.x * apq);
+                const double rqp = fma(ra.y, app, ra.x * aqp), rqq = fma(ra.y, apq, ra.x * aqq);
+                const double npp = fma(-rb.y, rpq, rb.x * rpp), nqq = fma(rb.y, rqp, rb.x * rqq);
+                double npq = fma(rb.y, rpp, rb.x * rpq), nqp = fma(-rb.y, rqq, rb.x * rqp);
+                if (my_ia_c == my_ib_c) { npq = 0.0; nqp = 0.0; }  // the pivot is annihilated exactly
+                const double y0p = fma(-r0.y, x0q, r0.x * x0p), y0q = fma(r0.y, x0p, r0.x * x0q);
+                const double y1p = fma(-r1.y, x1q, r1.x * x1p), y1q = fma(r1.y, x1p, r1.x * x1q);
+                if (has_blk) { Ap[pb] = npp; Ap[qb] = npq; Aq[pb] = nqp; Aq[qb] = nqq; }
+                if (has_v0) { V0[vp0] = y0p; V0[vq0] = y0q; }
+                if (has_v1) { V1[vp1] = y1p; V1[vq1] = y1q; }
+                JSTAMP(4);
+                JSTAMP(5);
+            } else if (fast) {
                 // Branch-free: every load uses an in-range (clamped) address and is issued
                 // before the first use; only the stores are predicated.  (Predicated LOADS
                 // made the compiler fence each one with s_waitcnt: ~20 exposed LDS latencies.)
@@ -248,6 +292,108 @@ __device__ __forceinline__ int jacobi_eigh(double* A, double* V, int n, int ld, 
         }
     }
     JSTAMP_FLUSH
+    return sweep;
+}
+
+// Pipelined variant for even n <= 64 (m = n/2 pivots, 2m <= 64 lanes of wave 0).
+//
+// In pair-index space the entries the NEXT round's rotations need sit in a fixed set of 2m
+// blocks: the m diagonal blocks (all diagonal entries) and, for next pivot j, block
+// (j+1, j-1) (block (1,0) for j = 0, (2,0) for j = 1, (m-1, m-2) for j = m-1) -- the
+// tournament only rotates the ring.  Wave 0 updates exactly those blocks first, reads its own
+// results back (LDS operations of one wave execute in order) and forms the rotations of round
+// r+1 into the other table while waves 1.. apply round r to the remaining blocks and to V:
+// the ~700-cycle serial rotation chain leaves the critical path and one of the two barriers
+// per round goes away.
+__device__ __forceinline__ int jacobi_eigh_pipelined(double* A, double* V, int n, int ld, JacobiShared* sh,
+                                                     int max_sweeps) {
+    const int tid = threadIdx.x, nt = blockDim.x;
+    for (int i = tid; i < n * n; i += nt) V[(i / n) * ld + (i % n)] = (i / n == i % n) ? 1.0 : 0.0;
+    const int m = n / 2, ring = n - 1;
+    auto form_rotations = [&](int round, int buf) {  // lanes 0..m-1 of wave 0
+        int p, q;
+        pivot_pair(round, tid, n, p, q);
+        double c, s;
+        jacobi_rotation(A[p * ld + p], A[q * ld + q], A[p * ld + q], c, s);
+        sh->cs2[buf][tid] = make_double2(c, s);
+        sh->colw2[buf][tid] = p | (q << 16);
+        sh->roww2[buf][tid] = (p * ld) | ((q * ld) << 16);
+    };
+    auto update_block = [&](int ia, int ib, int buf, bool live) {
+        const int wr = sh->roww2[buf][ia], wc = sh->colw2[buf][ib];
+        const double2 ra = sh->cs2[buf][ia], rb = sh->cs2[buf][ib];
+        double* Ap = A + (wr & 0xffff);
+        double* Aq = A + (wr >> 16);
+        const int pb = wc & 0xffff, qb = wc >> 16;
+        const double app = Ap[pb], apq = Ap[qb], aqp = Aq[pb], aqq = Aq[qb];
+        const double rpp = fma(-ra.y, aqp, ra.x * app), rpq = fma(-ra.y, aqq, ra.x * apq);
+        const double rqp = fma(ra.y, app, ra.x * aqp), rqq = fma(ra.y, apq, ra.x * aqq);
+        const double npp = fma(-rb.y, rpq, rb.x * rpp), nqq = fma(rb.y, rqp, rb.x * rqq);
+        double npq = fma(rb.y, rpp, rb.x * rpq), nqp = fma(-rb.y, rqq, rb.x * rqp);
+        if (ia == ib) { npq = 0.0; nqp = 0.0; }  // the pivot is annihilated exactly
+        if (live) { Ap[pb] = npp; Ap[qb] = npq; Aq[pb] = nqp; Aq[qb] = nqq; }
+    };
+    // static roles
+    const int my_ia = tid / m, my_ib = tid - my_ia * m;
+    const bool priority = (my_ib == my_ia) || (my_ia >= 2 && my_ib == my_ia - 2) || (my_ia == 1 && my_ib == 0) ||
+                          (my_ia == m - 1 && my_ib == m - 2);
+    const bool has_blk = tid < m * m && !priority;
+    const int my_ia_c = tid < m * m ? my_ia : 0, my_ib_c = tid < m * m ? my_ib : 0;
+    // wave 0: lane l < m -> diagonal block l; lane m + j -> the block holding next pivot j
+    int pr_ia = 0, pr_ib = 0;
+    const bool has_pr = tid < 2 * m;
+    if (tid < m) { pr_ia = tid; pr_ib = tid; }
+    else if (tid < 2 * m) {
+        const int j = tid - m;
+        if (j == 0) { pr_ia = 1; pr_ib = 0; }
+        else if (j == 1) { pr_ia = 2; pr_ib = 0; }
+        else if (j == m - 1) { pr_ia = m - 1; pr_ib = m - 2; }
+        else { pr_ia = j + 1; pr_ib = j - 1; }
+    }
+    const int v_ib0 = tid / n, v_r0 = tid - v_ib0 * n;
+    const int v_ib1 = (tid + nt) / n, v_r1 = (tid + nt) - v_ib1 * n;
+    const bool has_v0 = tid < m * n, has_v1 = tid + nt < m * n;
+    const int v_ib0_c = has_v0 ? v_ib0 : 0, v_ib1_c = has_v1 ? v_ib1 : 0, v_r1_c = has_v1 ? v_r1 : 0;
+    __syncthreads();
+    int buf = 0, round = 0;
+    if (tid < m) form_rotations(0, 0);
+    __syncthreads();
+    int sweep = 0;
+    for (; sweep < max_sweeps; ++sweep) {
+        double off = 0.0, dia = 0.0;
+        for (int i = tid; i < n * n; i += nt) {
+            const int r = i / n, c = i - r * n;
+            const double v = A[r * ld + c];
+            if (r == c) dia = fma(v, v, dia); else off = fma(v, v, off);
+        }
+        off = block_sum(off, sh);
+        dia = block_sum(dia, sh);
+        const double tol = (double)n * 2.220446049250313e-16;  // see jacobi_eigh
+        if (off <= tol * tol * (dia + off) || off == 0.0) break;
+        for (int rr = 0; rr < ring; ++rr) {
+            const int next_round = round + 1 == ring ? 0 : round + 1;
+            if (tid < 64) {  // wave 0 (uniform branch)
+                update_block(pr_ia, pr_ib, buf, has_pr);
+                if (tid < m) form_rotations(next_round, buf ^ 1);
+            }
+            update_block(my_ia_c, my_ib_c, buf, has_blk);
+            {
+                const int w0 = sh->colw2[buf][v_ib0_c], w1 = sh->colw2[buf][v_ib1_c];
+                const double2 r0 = sh->cs2[buf][v_ib0_c], r1 = sh->cs2[buf][v_ib1_c];
+                double* V0 = V + v_r0 * ld;
+                double* V1 = V + v_r1_c * ld;
+                const int vp0 = w0 & 0xffff, vq0 = w0 >> 16, vp1 = w1 & 0xffff, vq1 = w1 >> 16;
+                const double x0p = V0[vp0], x0q = V0[vq0], x1p = V1[vp1], x1q = V1[vq1];
+                const double y0p = fma(-r0.y, x0q, r0.x * x0p), y0q = fma(r0.y, x0p, r0.x * x0q);
+                const double y1p = fma(-r1.y, x1q, r1.x * x1p), y1q = fma(r1.y, x1p, r1.x * x1q);
+                if (has_v0) { V0[vp0] = y0p; V0[vq0] = y0q; }
+                if (has_v1) { V1[vp1] = y1p; V1[vq1] = y1q; }
+            }
+            __syncthreads();
+            buf ^= 1;
+            round = next_round;
+        }
+    }
     return sweep;
 }
 
