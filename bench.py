@@ -32,6 +32,10 @@ sys.path.insert(0, str(ROOT))
 N_FRAMES, N_FEATURES, TICA_DIM, K_STATES, LAG, KMEANS_ITERS = 1_000_000, 64, 10, 500, 10, 10
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s
 FP64_MFMA_PEAK_TF = 78.6       # MI355X fp64 matrix (= vector) peak
+# HBM-side bytes per launch of the dominant kernel at the default workload, from the PMC passes in
+# profiles/r01_pmc_hbm.md (2 x FETCH_SIZE + WRITE_SIZE, the gfx950 correction of the guide):
+# reads of Y (80 MB) + next-group prefetch + the atomics flush of the member sums
+KMEANS_ACCUM_TRAFFIC_BYTES = (2 * 44335 + 10571) * 1024
 
 
 def cpu_baseline(X: np.ndarray) -> dict:
@@ -163,7 +167,9 @@ def main() -> None:
                        "parallelism": f"shards{world}"},
             "roofline": {"kernel": "kmeans_mfma_kernel<double,3,4,true> (assign + accumulate)", "bound": "mfma",
                          "achieved": achieved_tf, "peak": FP64_MFMA_PEAK_TF, "unit": "TFLOP/s",
-                         "frac": achieved_tf / FP64_MFMA_PEAK_TF, "traffic": None,
+                         "frac": achieved_tf / FP64_MFMA_PEAK_TF,
+                         "traffic": KMEANS_ACCUM_TRAFFIC_BYTES if n == N_FRAMES else None,
+                         "traffic_unit": "bytes per launch (rocprofv3 PMC, profiles/r01_pmc_hbm.md)",
                          "launch_ms": acc_ms_avg, "launches_timed": len(acc_ms),
                          "algorithmic_flops_per_launch": flops_per_launch},
         }
