@@ -188,100 +188,41 @@ __device__ double spec_block_sum(double v, SpecShared* sh) {
     return sh->bc;
 }
 
-// W = T' Z   (W[j][c] = sum_i T[i][j] Z[i][c]); T reads are coalesced over j.
-__device__ void spec_apply_Tt(const double* __restrict__ T, int ld, int n, int p, const double* __restrict__ Z,
-                              double* __restrict__ W, double* lds_part /* [groups][64][p] unused for groups == 1 */) {
-    const int tid = threadIdx.x;
-    const int lane = tid & 63, wave = tid >> 6, n_waves = blockDim.x >> 6;
-    // each wave owns column tiles of 64 states; within the tile lanes = j
-    for (int j0 = wave * 64; j0 < n; j0 += n_waves * 64) {
-        const int j = j0 + lane;
-        for (int c0 = 0; c0 < p; c0 += 8) {
-            double acc[8];
-#pragma unroll
-            for (int c = 0; c < 8; ++c) acc[c] = 0.0;
-            if (j < n) {
-                for (int i = 0; i < n; ++i) {
-                    const double t = T[(size_t)i * ld + j];
-                    const double* zr = Z + (size_t)i * p + c0;
-#pragma unroll
-                    for (int c = 0; c < 8; ++c)
-                        if (c0 + c < p) acc[c] = fma(t, zr[c], acc[c]);
-                }
-#pragma unroll
-                for (int c = 0; c < 8; ++c)
-                    if (c0 + c < p) W[(size_t)j * p + c0 + c] = acc[c];
-            }
-        }
-    }
-    (void)lds_part;
-    __syncthreads();
-}
-
-// M[a][b] = sum_j A[j][a] B[j][b]  (p x p), every thread block-strided over j
-__device__ void spec_gram(const double* __restrict__ A, const double* __restrict__ B, int n, int p, double* M,
-                          SpecShared* sh) {
-    for (int a = 0; a < p; ++a)
-        for (int b = 0; b < p; ++b) {
-            double acc = 0.0;
-            for (int j = threadIdx.x; j < n; j += blockDim.x) acc = fma(A[(size_t)j * p + a], B[(size_t)j * p + b], acc);
-            acc = spec_block_sum(acc, sh);
-            if (threadIdx.x == 0) M[a * p + b] = acc;
-        }
-    __syncthreads();
-}
-
-// faster Gram: thread (pair, group) partial sums, then fixed-order reduce through LDS scratch in W tail
-__device__ void spec_gram_fast(const double* __restrict__ A, const double* __restrict__ B, int n, int p, double* M,
-                               double* scratch /* >= blockDim.x doubles, global */) {
+// Gram matrix M = A'B (p x p): thread (pair, group) partial sums over rows j = g, g + groups, ...,
+// then a fixed-order reduce through LDS scratch.  Inlined so that an LDS-resident operand keeps
+// its address space (ds_read instead of flat loads); 32-bit strength-reduced offsets -- the
+// single workgroup is bound by instruction issue, not by the 2 n p^2 flops.
+__device__ __forceinline__ void spec_gram_fast(const double* __restrict__ A, const double* __restrict__ B, int n, int p,
+                                               double* M, double* scratch /* >= blockDim.x doubles (LDS) */) {
     const int pairs = p * p;
     const int groups = blockDim.x / pairs;  // >= 1 because p <= 32 and blockDim = 1024
     const int tid = threadIdx.x;
     const int pr = tid % pairs, g = tid / pairs;
-    double acc = 0.0;
     if (g < groups) {
         const int a = pr / p, b = pr - a * p;
-        for (int j = g; j < n; j += groups) acc = fma(A[(size_t)j * p + a], B[(size_t)j * p + b], acc);
-        scratch[tid] = acc;
+        // 8 independent row pairs in flight (the sum order stays fixed: 8 interleaved partial
+        // sums, then their sum)
+        double part[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+        const int step = groups * p, end = n * p;
+        int off = g * p;
+        for (; off + 7 * step < end; off += 8 * step) {
+            double av[8], bv[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                av[u] = A[off + u * step + a];
+                bv[u] = B[off + u * step + b];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) part[u] = fma(av[u], bv[u], part[u]);
+        }
+        for (; off < end; off += step) part[0] = fma(A[off + a], B[off + b], part[0]);
+        scratch[tid] = ((part[0] + part[1]) + (part[2] + part[3])) + ((part[4] + part[5]) + (part[6] + part[7]));
     }
     __syncthreads();
     if (tid < pairs) {
         double t = 0.0;
         for (int gg = 0; gg < groups; ++gg) t += scratch[gg * pairs + tid];
         M[tid] = t;
-    }
-    __syncthreads();
-}
-
-// Cholesky G = R'R (upper R) by one wave, lanes over columns; then Z = W R^-1 row-wise.
-__device__ void spec_cholqr(double* G, double* R, int p, const double* __restrict__ W, double* __restrict__ Z, int n) {
-    const int tid = threadIdx.x;
-    if (tid < 64) {
-        const int j = tid;
-        for (int c = 0; c < p; ++c) {
-            // R[c][j] for j >= c
-            double v = 0.0;
-            if (j < p && j >= c) {
-                v = G[c * p + j];
-                for (int m = 0; m < c; ++m) v = fma(-R[m * p + c], R[m * p + j], v);
-            }
-            double diag = __shfl(v, c, 64);
-            if (!(diag > 1e-300)) diag = 1e-300;  // rank-deficient basis: keep going, column dies out
-            const double rcc = sqrt(diag);
-            if (j < p) R[c * p + j] = j > c ? v / rcc : (j == c ? rcc : 0.0);
-            __builtin_amdgcn_wave_barrier();
-        }
-    }
-    __syncthreads();
-    for (int i = tid; i < n; i += blockDim.x) {
-        double z[kMaxP];
-#pragma unroll 1
-        for (int c = 0; c < p; ++c) {
-            double v = W[(size_t)i * p + c];
-            for (int m = 0; m < c; ++m) v = fma(-z[m], R[m * p + c], v);
-            z[c] = v / R[c * p + c];
-            Z[(size_t)i * p + c] = z[c];
-        }
     }
     __syncthreads();
 }
@@ -306,30 +247,175 @@ __device__ void spec_ritz(SpecShared* sh, int p, double* out_re, double* out_im)
     __syncthreads();
 }
 
-__global__ __launch_bounds__(kSolveThreads) void spectrum_kernel(SpecArgs ar) {
+// ---- multi-workgroup driver --------------------------------------------------------------
+// One subspace-iteration step is  W = T'Z  (the only O(n^2 p) part: spread over the chip) followed
+// by a light single-workgroup step per matrix (sum of the row-split partials, and every few
+// steps Gram + Cholesky-QR; Rayleigh-Ritz / residuals / pi / implied timescales at the end).
+// T is stochastic (|lambda| <= 1) so the basis needs no rescaling between orthogonalisations.
+constexpr int kSpecSplits = 8;        // row splits of T per apply launch (fixed-order partial sums)
+constexpr int kApplyThreads = 256;    // 4 waves = 4 tiles of 64 columns
+
+// partial[s][j][c] = sum_{i in split s} T[i][j] Z[i][c]
+template <int PC>
+__global__ __launch_bounds__(kApplyThreads) void spec_apply_kernel(SpecArgs ar, const double* __restrict__ Zin_all,
+                                                                  double* __restrict__ partial_all, size_t part_stride) {
+    const int b = blockIdx.z;
+    const int n = ar.n_ptr ? ar.n_ptr[b] : ar.n_fixed;
+    if (n <= 0) return;
+    const int p = min(ar.p, n);
+    const double* T = ar.T + (size_t)b * ar.t_stride;
+    const double* Z = Zin_all + (size_t)b * ar.zw_stride;
+    double* part = partial_all + (size_t)b * part_stride + (size_t)blockIdx.y * ((size_t)ar.n_fixed * ar.p);
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int j = (blockIdx.x * 4 + wave) * 64 + lane;
+    const int rows = (n + kSpecSplits - 1) / kSpecSplits;
+    const int i0 = blockIdx.y * rows, i1 = min(n, i0 + rows);
+    double acc[PC];
+#pragma unroll
+    for (int c = 0; c < PC; ++c) acc[c] = 0.0;
+    const int jc = j < n ? j : n - 1;
+    int i = i0;
+    for (; i + 7 < i1; i += 8) {  // 8 independent T loads in flight per lane
+        double t[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) t[u] = T[(size_t)(i + u) * ar.ld + jc];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const double* zr = Z + (size_t)(i + u) * p;  // wave-uniform: scalar loads
+#pragma unroll
+            for (int c = 0; c < PC; ++c)
+                if (c < p) acc[c] = fma(t[u], zr[c], acc[c]);
+        }
+    }
+    for (; i < i1; ++i) {
+        const double t = T[(size_t)i * ar.ld + jc];
+        const double* zr = Z + (size_t)i * p;
+#pragma unroll
+        for (int c = 0; c < PC; ++c)
+            if (c < p) acc[c] = fma(t, zr[c], acc[c]);
+    }
+    if (j < n) {
+#pragma unroll
+        for (int c = 0; c < PC; ++c)
+            if (c < p) part[(size_t)j * p + c] = acc[c];
+    }
+}
+
+// Diagnostic build only (tools/probe/spec_stamp_probe.hip)
+#ifdef MSM_SPEC_STAMPS
+__device__ unsigned long long g_spec_stamps[8];
+#define SSTAMP(i) do { unsigned long long t__ = __builtin_amdgcn_s_memtime(); if (threadIdx.x == 0) g_spec_stamps[i] += t__ - slast__; slast__ = t__; } while (0)
+#define SSTAMP_INIT unsigned long long slast__ = __builtin_amdgcn_s_memtime();
+#else
+#define SSTAMP(i)
+#define SSTAMP_INIT
+#endif
+
+// mode bits
+constexpr int kStepInit = 1;     // seeded basis -> orthonormal Z (no partials involved)
+constexpr int kStepOrtho = 2;    // Z <- orth(W)
+constexpr int kStepCheck = 4;    // H = Z'W and "previous" Ritz values (needs an orthonormal Z)
+constexpr int kStepFinish = 8;   // Rayleigh-Ritz, residuals, pi, implied timescales
+
+// Z = W R^-1 for upper-triangular R (p x p in LDS): R^-1 by one wave (lane = column), then a
+// p-term dot product per element.
+__device__ __forceinline__ void spec_apply_rinv(SpecShared* sh, int p, const double* __restrict__ W,
+                                                double* __restrict__ Z, int n) {
+    const int tid = threadIdx.x;
+    double* Rinv = sh->Hw;  // p x p
+    if (tid < 64) {
+        const int c = tid;
+        if (c < p) {
+            for (int m = 0; m < p; ++m) Rinv[m * p + c] = 0.0;
+            Rinv[c * p + c] = 1.0 / sh->R[c * p + c];
+            for (int m = c - 1; m >= 0; --m) {
+                double a = 0.0;
+                for (int l = m + 1; l <= c; ++l) a = fma(sh->R[m * p + l], Rinv[l * p + c], a);
+                Rinv[m * p + c] = -a / sh->R[m * p + m];
+            }
+        }
+    }
+    __syncthreads();
+    // one row per thread: the whole row of W is requested at once (independent loads), every
+    // output is a short FMA chain over registers and the LDS copy of R^-1
+    for (int i = tid; i < n; i += blockDim.x) {
+        double w[kMaxP];
+        const int row = i * p;
+#pragma unroll
+        for (int m = 0; m < kMaxP; ++m) w[m] = m < p ? W[row + m] : 0.0;
+#pragma unroll
+        for (int c8 = 0; c8 < kMaxP; c8 += 8) {
+            if (c8 >= p) break;
+#pragma unroll
+            for (int c = c8; c < c8 + 8; ++c) {
+                if (c < p) {
+                    double v = 0.0;
+#pragma unroll
+                    for (int m = 0; m <= c; ++m) v = fma(w[m], Rinv[m * p + c], v);
+                    Z[row + c] = v;
+                }
+            }
+        }
+    }
+    __syncthreads();
+}
+
+__device__ void spec_cholesky(SpecShared* sh, int p) {
+    const int tid = threadIdx.x;
+    if (tid < 64) {
+        const int j = tid;
+        for (int c = 0; c < p; ++c) {
+            double v = 0.0;
+            if (j < p && j >= c) {
+                v = sh->G[c * p + j];
+                for (int m = 0; m < c; ++m) v = fma(-sh->R[m * p + c], sh->R[m * p + j], v);
+            }
+            double diag = __shfl(v, c, 64);
+            if (!(diag > 1e-300)) diag = 1e-300;  // rank-deficient basis: keep going, column dies out
+            const double rcc = sqrt(diag);
+            if (j < p) sh->R[c * p + j] = j > c ? v / rcc : (j == c ? rcc : 0.0);
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+    __syncthreads();
+}
+
+// Z: current (orthonormal unless between orthogonalisations) basis; Wb: the other buffer.
+template <bool lds_w>
+__global__ __launch_bounds__(kSolveThreads) void spec_step_kernel(SpecArgs ar, int mode, double* __restrict__ Zall,
+                                                                 double* __restrict__ Wall,
+                                                                 const double* __restrict__ partial_all,
+                                                                 size_t part_stride) {
     __shared__ SpecShared sh;
+    extern __shared__ __attribute__((aligned(16))) double w_lds[];  // n_fixed * p doubles when lds_w
     const int b = blockIdx.x;
     const int tid = threadIdx.x;
     const int n = ar.n_ptr ? ar.n_ptr[b] : ar.n_fixed;
-    const double* T = ar.T + (size_t)b * ar.t_stride;
-    double* Z = ar.Z + (size_t)b * ar.zw_stride;
-    double* W = ar.W + (size_t)b * ar.zw_stride;
+    double* Z = Zall + (size_t)b * ar.zw_stride;
+    double* Wg = Wall + (size_t)b * ar.zw_stride;
+    // A lone workgroup pays ~2 us for every dependent trip to memory another XCD has just
+    // written: W = T'Z is summed into LDS in one round of loads and stays there for the Gram
+    // matrix, the triangular solve and the residuals.
+    double* W = lds_w ? w_lds : Wg;
     double* ritz = ar.ritz + (size_t)b * 4 * kMaxP;
     if (tid == 0) sh.status = 0;
     __syncthreads();
     if (n <= 0) {
-        if (tid == 0) { ar.change[b] = 0.0; ar.status[b] = 0; }
-        for (int i = tid; i < 4 * kMaxP; i += blockDim.x) ritz[i] = 0.0;
-        for (int i = tid; i < ar.n_its; i += blockDim.x) {
-            ar.its_eig[(size_t)b * ar.n_its + i] = __builtin_nan("");
-            ar.its_ts[(size_t)b * ar.n_its + i] = __builtin_nan("");
+        if (mode & kStepFinish) {
+            if (tid == 0) { ar.change[b] = 0.0; ar.status[b] = 0; }
+            for (int i = tid; i < 4 * kMaxP; i += blockDim.x) ritz[i] = 0.0;
+            for (int i = tid; i < ar.n_its; i += blockDim.x) {
+                ar.its_eig[(size_t)b * ar.n_its + i] = __builtin_nan("");
+                ar.its_ts[(size_t)b * ar.n_its + i] = __builtin_nan("");
+            }
         }
         return;
     }
     const int p = min(ar.p, n);
-    if (ar.init) {
+    if (mode & kStepInit) {
         for (int e = tid; e < n * p; e += blockDim.x) {
-            const int i = e / p, c = e - i * p;
+            const int c = e % p;
             double v;
             if (c == 0) v = 1.0;
             else {
@@ -342,28 +428,65 @@ __global__ __launch_bounds__(kSolveThreads) void spectrum_kernel(SpecArgs ar) {
             W[e] = v;
         }
         __syncthreads();
-        spec_gram_fast(W, W, n, p, sh.G, Z);  // Z is free scratch here (n*p >= p*p*groups? use safe path below)
-        spec_cholqr(sh.G, sh.R, p, W, Z, n);
+        spec_gram_fast(W, W, n, p, sh.G, sh.Hw);
+        spec_cholesky(&sh, p);
+        spec_apply_rinv(&sh, p, W, Z, n);
+        return;
     }
-    double* scratch = W + (size_t)n * p;  // tail of the W allocation (>= kSolveThreads doubles)
-    for (int it = 0; it < ar.n_iter; ++it) {
-        const bool check_prev = (it == ar.n_iter - 1 - ar.check_gap);
-        spec_apply_Tt(T, ar.ld, n, p, Z, W, nullptr);
-        if (check_prev) {
-            spec_gram_fast(Z, W, n, p, sh.H, scratch);
-            spec_ritz(&sh, p, ritz + 2 * kMaxP, ritz + 3 * kMaxP);
+    SSTAMP_INIT
+    // W = sum of the row-split partials, fixed order
+    {
+        const double* part = partial_all + (size_t)b * part_stride;
+        const size_t split_stride = (size_t)ar.n_fixed * ar.p;
+        int e = tid;
+        for (; e + (int)blockDim.x < n * p; e += 2 * blockDim.x) {  // 2 x kSpecSplits loads in flight
+            double v0[kSpecSplits], v1[kSpecSplits];
+#pragma unroll
+            for (int sp = 0; sp < kSpecSplits; ++sp) {
+                v0[sp] = part[sp * split_stride + e];
+                v1[sp] = part[sp * split_stride + e + blockDim.x];
+            }
+            double a0 = 0.0, a1 = 0.0;
+#pragma unroll
+            for (int sp = 0; sp < kSpecSplits; ++sp) { a0 += v0[sp]; a1 += v1[sp]; }
+            W[e] = a0;
+            W[e + blockDim.x] = a1;
         }
-        spec_gram_fast(W, W, n, p, sh.G, scratch);
-        spec_cholqr(sh.G, sh.R, p, W, Z, n);
+        for (; e < n * p; e += blockDim.x) {
+            double v = 0.0;
+#pragma unroll
+            for (int sp = 0; sp < kSpecSplits; ++sp) v += part[sp * split_stride + e];
+            W[e] = v;
+        }
+        __syncthreads();
+        if (lds_w && !(mode & (kStepOrtho | kStepFinish))) {  // plain power step: the next apply reads global
+            for (int q = tid; q < n * p; q += blockDim.x) Wg[q] = W[q];
+        }
     }
-    // Rayleigh-Ritz on the final basis
-    spec_apply_Tt(T, ar.ld, n, p, Z, W, nullptr);
-    spec_gram_fast(Z, W, n, p, sh.H, scratch);
+    SSTAMP(0);
+    if (mode & kStepCheck) {
+        spec_gram_fast(Z, W, n, p, sh.H, sh.Hw);
+        spec_ritz(&sh, p, ritz + 2 * kMaxP, ritz + 3 * kMaxP);
+    }
+    if (mode & kStepOrtho) {
+        spec_gram_fast(W, W, n, p, sh.G, sh.Hw);
+        SSTAMP(1);
+        spec_cholesky(&sh, p);
+        SSTAMP(2);
+        spec_apply_rinv(&sh, p, W, Z, n);
+        SSTAMP(3);
+    }
+    if (!(mode & kStepFinish)) {
+        if (tid == 0 && sh.status) ar.status[b] = sh.status;
+        return;
+    }
+    // ---- Rayleigh-Ritz on the (orthonormal) basis Z with W = T'Z
+    spec_gram_fast(Z, W, n, p, sh.H, sh.Hw);
     spec_ritz(&sh, p, ritz, ritz + kMaxP);
     for (int i = p + tid; i < kMaxP; i += blockDim.x) { ritz[i] = 0.0; ritz[kMaxP + i] = 0.0; }
     __syncthreads();
     // Convergence measure: the true residual ||T'x - theta x|| / ||x|| of every watched REAL
-    // Ritz pair (x = Z y, T'x = W y); for complex values, the change over the last check gap.
+    // Ritz pair (x = Z y, T'x = W y); for complex values, the change since the last check.
     // (Changes of Ritz values alone stagnate on clustered spectra and would stop too early.)
     {
         const int nw = min(ar.n_watch, p);
@@ -373,7 +496,7 @@ __global__ __launch_bounds__(kSolveThreads) void spectrum_kernel(SpecArgs ar) {
             if (th_im != 0.0) {
                 const double dr = th_re - ritz[2 * kMaxP + wv], di = th_im - ritz[3 * kMaxP + wv];
                 const double mag = sqrt(th_re * th_re + th_im * th_im);
-                const double ch = (ar.n_iter > ar.check_gap) ? sqrt(dr * dr + di * di) / fmax(mag, 1e-300) : 1.0;
+                const double ch = ar.check_gap > 0 ? sqrt(dr * dr + di * di) / fmax(mag, 1e-300) : 1.0;
                 worst = fmax(worst, ch);
                 continue;
             }
@@ -444,7 +567,7 @@ __global__ __launch_bounds__(kSolveThreads) void spectrum_kernel(SpecArgs ar) {
             ar.its_ts[(size_t)b * n_its + i] = ts;
         }
     }
-    if (tid == 0) ar.status[b] = sh.status;
+    if (tid == 0 && sh.status) ar.status[b] = sh.status;
 }
 
 }  // namespace
@@ -501,7 +624,8 @@ msm_status msm_embed_full(msm_ctx* ctx, const double* d_T_active, const double* 
 }
 
 size_t msm_spectrum_workspace_bytes(int n_max, int p, int batch) {
-    const size_t per = 2 * ((size_t)n_max * p + kSolveThreads) * sizeof(double) + 4 * kMaxP * sizeof(double);
+    // two basis buffers (+ reduction scratch tail) and the row-split partial products
+    const size_t per = (2 * ((size_t)n_max * p + kSolveThreads) + (size_t)kSpecSplits * n_max * p) * sizeof(double);
     return per * (size_t)batch + 256;
 }
 
@@ -519,13 +643,64 @@ msm_status msm_spectrum(msm_ctx* ctx, const double* d_T, int64_t t_stride, int l
     ar.T = d_T; ar.t_stride = (size_t)t_stride; ar.ld = ld; ar.n_ptr = d_n; ar.n_fixed = n_max;
     ar.p = p; ar.n_iter = n_iter; ar.init = init; ar.seed = seed;
     const size_t zw = (size_t)n_max * p + kSolveThreads;
-    ar.Z = (double*)d_workspace;
-    ar.W = ar.Z + zw * batch;
+    double* bufA = (double*)d_workspace;              // the orthonormal basis lives here between calls
+    double* bufB = bufA + zw * batch;
+    double* partial = bufB + zw * batch;
+    const size_t part_stride = (size_t)kSpecSplits * n_max * p;
+    ar.Z = bufA; ar.W = bufB;
     ar.zw_stride = zw;
     ar.ritz = d_ritz; ar.pi = d_pi; ar.pi_stride = (size_t)pi_stride; ar.change = d_change;
-    ar.n_watch = n_watch; ar.check_gap = n_iter >= 8 ? 4 : (n_iter > 1 ? 1 : 0);
+    ar.n_watch = n_watch;
     ar.status = d_status; ar.n_its = n_its; ar.lags = d_lags; ar.its_eig = d_its_eig; ar.its_ts = d_its_ts;
-    hipLaunchKernelGGL(spectrum_kernel, dim3(batch), dim3(kSolveThreads), 0, ctx->stream, ar);
+    // orthogonalise every kOrthoEvery applications and always after the last one; compare the
+    // complex Ritz values against those right after an earlier orthogonalisation.  Every step:
+    // Cholesky-QR squares the condition number of W, and a metastable T damps the fast directions
+    // by lambda^q -- already q = 6 un-orthogonalised applications broke the factorisation.
+    constexpr int kOrthoEvery = 1;
+    int check_it = -1;
+    for (int it = 0; it + 4 < n_iter || (it + 1 < n_iter && check_it < 0); ++it)
+        if (it == 0 || (it % kOrthoEvery) == 0) check_it = it;  // basis orthonormal when step `it` starts
+    ar.check_gap = check_it >= 0 ? n_iter - check_it : 0;
+    auto apply = [&](const double* zin) {
+        const dim3 grid((unsigned)((n_max + 255) / 256), kSpecSplits, (unsigned)batch);
+        if (p <= 8) hipLaunchKernelGGL(spec_apply_kernel<8>, grid, dim3(kApplyThreads), 0, ctx->stream, ar, zin, partial, part_stride);
+        else if (p <= 16) hipLaunchKernelGGL(spec_apply_kernel<16>, grid, dim3(kApplyThreads), 0, ctx->stream, ar, zin, partial, part_stride);
+        else if (p <= 24) hipLaunchKernelGGL(spec_apply_kernel<24>, grid, dim3(kApplyThreads), 0, ctx->stream, ar, zin, partial, part_stride);
+        else hipLaunchKernelGGL(spec_apply_kernel<32>, grid, dim3(kApplyThreads), 0, ctx->stream, ar, zin, partial, part_stride);
+    };
+    const size_t w_bytes = (size_t)n_max * p * sizeof(double);
+    const bool lds_w = w_bytes <= 96 * 1024;
+    if (lds_w && w_bytes > 12 * 1024)
+        MSM_HIP(ctx, hipFuncSetAttribute((const void*)spec_step_kernel<true>,
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)w_bytes));
+    auto step = [&](int mode, double* z, double* w) {
+        if (lds_w && !(mode & kStepInit))
+            hipLaunchKernelGGL(spec_step_kernel<true>, dim3(batch), dim3(kSolveThreads), w_bytes, ctx->stream, ar, mode,
+                               z, w, partial, part_stride);
+        else
+            hipLaunchKernelGGL(spec_step_kernel<false>, dim3(batch), dim3(kSolveThreads), 0, ctx->stream, ar, mode, z,
+                               w, partial, part_stride);
+    };
+    MSM_HIP(ctx, hipMemsetAsync(d_status, 0, sizeof(int32_t) * batch, ctx->stream));
+    if (init) step(kStepInit, bufA, bufB);
+    MSM_CHECK_LAUNCH(ctx);
+    // invariant at the top of an iteration: the current basis is in `cur`
+    double* cur = bufA;
+    double* other = bufB;
+    for (int it = 0; it < n_iter; ++it) {
+        apply(cur);
+        const bool ortho = (it % kOrthoEvery) == kOrthoEvery - 1 || it == n_iter - 1;
+        const int mode = (it == check_it ? kStepCheck : 0) | (ortho ? kStepOrtho : 0);
+        step(mode, cur, other);   // sum -> other; ortho: orth(other) -> cur
+        if (!ortho) std::swap(cur, other);
+        MSM_CHECK_LAUNCH(ctx);
+    }
+    if (cur != bufA) {  // keep the persistent basis in bufA
+        MSM_HIP(ctx, hipMemcpyAsync(bufA, cur, zw * batch * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+        cur = bufA; other = bufB;
+    }
+    apply(cur);
+    step(kStepFinish, cur, other);
     MSM_CHECK_LAUNCH(ctx);
     return MSM_OK;
 }

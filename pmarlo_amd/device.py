@@ -469,8 +469,8 @@ class Engine:
         return T_full, pi_full
 
     def spectrum(self, T: DeviceArray, *, n: DeviceArray | None = None, n_its: int = 0, lags=None,
-                 p: int | None = None, want_pi: bool = True, tol: float = 1e-9, n_iter: int = 60,
-                 max_launches: int = 40, seed: int = 0, allow_unconverged: bool = False) -> dict:
+                 p: int | None = None, want_pi: bool = True, tol: float = 1e-9, n_iter: int = 24,
+                 max_launches: int = 100, seed: int = 0, allow_unconverged: bool = False) -> dict:
         """Leading Ritz values / stationary distribution / implied timescales of one matrix
         [k,k] or a batch [B,k,k] of packed row-stochastic matrices (orders in `n`, int32 [B])."""
         batched = len(T.shape) == 3

@@ -58,6 +58,12 @@ def main():
     cnts = eng.empty((k, k), np.int64)
     prs = eng.empty((1,), np.int64)
     res["count_transitions"] = timeit(eng, lambda: eng.count_transitions(lab, k, lag, out=cnts, pairs=prs))
+    tm = eng.transition_matrix(cnts, mode=1)
+    import time as _t
+    eng.sync(); t0 = _t.perf_counter()
+    spec = eng.spectrum(tm["T"], n=tm["n_active"], n_its=5, lags=[float(lag)])
+    eng.sync(); dt = _t.perf_counter() - t0
+    print(f"spectrum (ITS, k={k}): {dt * 1e3:.2f} ms wall, launches {spec['launches']}, residual {spec['residual']}")
     print(f"config n={n} F={F} d={d} k={k} lag={lag}; eigs", eig.to_host()[:4])
     flops = {"lagged_moments": 3 * F * F * n, "kmeans_assign": 2 * k * d * n}
     bytes_ = {"moments": n * F * 4, "project": n * (F * 4 + d * 8), "count_transitions": n * 4,
