@@ -255,7 +255,8 @@ msm_status msm_eigh(msm_ctx* ctx, const double* d_a, int n, double* d_w, double*
  * which is sklearn's argmin_j(|c_j|^2 - 2 x.c_j) (lloyd_iter_chunked_dense)
  * with the summation order pinned; oracle/msm_oracle.c restates it with C fma().
  *
- * d_x  [n, ld] dtype   d_centers f64 [k, d]   d_mean/d_std f64 [d] or NULL
+ * d_x  [n, ld] dtype   d_centers f64 [k, d]   d_mean/d_std f64 [d] or NULL   (1 <= d <= 256;
+ * wider frames return MSM_ERR_UNSUPPORTED)
  * d_labels int32 [n]   d_mindist f64 [n] or NULL (dist_j + |z|^2 >= 0 clipped,
  * i.e. the squared distance to the chosen centre, for inertia)
  */

@@ -17,99 +17,9 @@
 namespace {
 
 constexpr int kThreads = 256;
-constexpr int kCentreLdsBudget = 48 * 1024;  // bytes of centre tile (+ norms) per workgroup
 
 template <typename T>
 __device__ __forceinline__ double load_as_f64(const T* p) { return (double)(*p); }
-
-// D = padded feature count (compile time), R = frames per lane.
-template <typename T, int D, int R>
-__global__ __launch_bounds__(kThreads) void kmeans_assign_kernel(
-    const T* __restrict__ x, int64_t n, int d, int64_t ld, const double* __restrict__ centers, int k,
-    const double* __restrict__ mean, const double* __restrict__ stdv, int tile_k,
-    int32_t* __restrict__ labels, double* __restrict__ mindist) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    double* cs = reinterpret_cast<double*>(smem_raw);  // [tile_k][D]
-    double* csq = cs + (size_t)tile_k * D;              // [tile_k]
-
-    const int tid = threadIdx.x;
-    const int64_t frames_per_block = (int64_t)kThreads * R;
-    const int64_t n_blocks = (n + frames_per_block - 1) / frames_per_block;
-
-    for (int64_t blk = blockIdx.x; blk < n_blocks; blk += gridDim.x) {
-        double z[R][D];
-        double zsq[R];
-        int64_t fidx[R];
-#pragma unroll
-        for (int r = 0; r < R; ++r) {
-            fidx[r] = blk * frames_per_block + (int64_t)r * kThreads + tid;
-            const bool ok = fidx[r] < n;
-            const T* row = x + (ok ? fidx[r] : 0) * ld;
-            double acc = 0.0;
-#pragma unroll
-            for (int f = 0; f < D; ++f) {
-                double v = 0.0;
-                if (f < d) {
-                    v = load_as_f64(row + f);
-                    if (mean) v = (v - mean[f]) / stdv[f];
-                }
-                z[r][f] = v;
-                acc = fma(v, v, acc);
-            }
-            zsq[r] = acc;
-        }
-        double best[R];
-        int bidx[R];
-#pragma unroll
-        for (int r = 0; r < R; ++r) { best[r] = __builtin_inf(); bidx[r] = 0; }
-
-        for (int k0 = 0; k0 < k; k0 += tile_k) {
-            const int kt = min(tile_k, k - k0);
-            __syncthreads();  // previous tile fully consumed
-            for (int i = tid; i < kt * D; i += kThreads) {
-                const int j = i / D, f = i - j * D;
-                cs[i] = f < d ? centers[(size_t)(k0 + j) * d + f] : 0.0;
-            }
-            __syncthreads();
-            for (int j = tid; j < kt; j += kThreads) {
-                double a = 0.0;
-#pragma unroll
-                for (int f = 0; f < D; ++f) a = fma(cs[j * D + f], cs[j * D + f], a);
-                csq[j] = a;
-            }
-            __syncthreads();
-#pragma unroll 2
-            for (int j = 0; j < kt; ++j) {
-                const double* c = cs + j * D;
-                double dot[R];
-#pragma unroll
-                for (int r = 0; r < R; ++r) dot[r] = 0.0;
-#pragma unroll
-                for (int f = 0; f < D; ++f) {
-                    const double cf = c[f];
-#pragma unroll
-                    for (int r = 0; r < R; ++r) dot[r] = fma(z[r][f], cf, dot[r]);
-                }
-                const double cq = csq[j];
-#pragma unroll
-                for (int r = 0; r < R; ++r) {
-                    const double dist = fma(-2.0, dot[r], cq);
-                    if (dist < best[r]) { best[r] = dist; bidx[r] = k0 + j; }
-                }
-            }
-        }
-#pragma unroll
-        for (int r = 0; r < R; ++r) {
-            if (fidx[r] < n) {
-                labels[fidx[r]] = bidx[r];
-                if (mindist) {
-                    const double m = best[r] + zsq[r];
-                    mindist[fidx[r]] = m > 0.0 ? m : 0.0;
-                }
-            }
-        }
-    }
-}
 
 // ---------------------------------------------------------------------------
 // fit: Lloyd iterations = (assign + accumulate) kernel, then a tiny update kernel.
@@ -229,103 +139,6 @@ __global__ void init_centers_kernel(const T* __restrict__ x, int64_t n, int d, i
     centers[i] = v;
 }
 
-// assign + accumulate.  sums int64 [k][d] (fixed point), counts int64 [k]; LDS-privatised
-// when k*(d+1) 8-byte bins fit beside the centre tile, otherwise global atomics.
-template <typename T, int D, int R, bool LDS_ACC>
-__global__ __launch_bounds__(kThreads) void kmeans_accum_kernel(
-    const T* __restrict__ x, int64_t n, int d, int64_t ld, const double* __restrict__ centers, int k,
-    const double* __restrict__ mean, const double* __restrict__ stdv, int tile_k, const FitState* __restrict__ st,
-    unsigned long long* __restrict__ sums, unsigned long long* __restrict__ counts) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    if (st->done != 0.0) return;
-    double* cs = reinterpret_cast<double*>(smem_raw);  // [tile_k][D]
-    double* csq = cs + (size_t)tile_k * D;              // [tile_k]
-    unsigned long long* lsum = reinterpret_cast<unsigned long long*>(csq + tile_k);  // [k][d] (LDS_ACC)
-    unsigned long long* lcnt = lsum + (size_t)k * d;                                  // [k]
-    const int tid = threadIdx.x;
-    const double scale = st->scale;
-    if constexpr (LDS_ACC) {
-        for (int i = tid; i < k * (d + 1); i += kThreads) lsum[i] = 0ull;
-    }
-    const int64_t frames_per_block = (int64_t)kThreads * R;
-    const int64_t n_blocks = (n + frames_per_block - 1) / frames_per_block;
-    for (int64_t blk = blockIdx.x; blk < n_blocks; blk += gridDim.x) {
-        double z[R][D];
-        int64_t fidx[R];
-#pragma unroll
-        for (int r = 0; r < R; ++r) {
-            fidx[r] = blk * frames_per_block + (int64_t)r * kThreads + tid;
-            const bool ok = fidx[r] < n;
-            const T* row = x + (ok ? fidx[r] : 0) * ld;
-#pragma unroll
-            for (int f = 0; f < D; ++f) {
-                double v = 0.0;
-                if (f < d) {
-                    v = load_as_f64(row + f);
-                    if (mean) v = (v - mean[f]) / stdv[f];
-                }
-                z[r][f] = v;
-            }
-        }
-        double best[R];
-        int bidx[R];
-#pragma unroll
-        for (int r = 0; r < R; ++r) { best[r] = __builtin_inf(); bidx[r] = 0; }
-        for (int k0 = 0; k0 < k; k0 += tile_k) {
-            const int kt = min(tile_k, k - k0);
-            __syncthreads();
-            for (int i = tid; i < kt * D; i += kThreads) {
-                const int j = i / D, f = i - j * D;
-                cs[i] = f < d ? centers[(size_t)(k0 + j) * d + f] : 0.0;
-            }
-            __syncthreads();
-            for (int j = tid; j < kt; j += kThreads) {
-                double a = 0.0;
-#pragma unroll
-                for (int f = 0; f < D; ++f) a = fma(cs[j * D + f], cs[j * D + f], a);
-                csq[j] = a;
-            }
-            __syncthreads();
-#pragma unroll 2
-            for (int j = 0; j < kt; ++j) {
-                const double* c = cs + j * D;
-                double dot[R];
-#pragma unroll
-                for (int r = 0; r < R; ++r) dot[r] = 0.0;
-#pragma unroll
-                for (int f = 0; f < D; ++f) {
-                    const double cf = c[f];
-#pragma unroll
-                    for (int r = 0; r < R; ++r) dot[r] = fma(z[r][f], cf, dot[r]);
-                }
-                const double cq = csq[j];
-#pragma unroll
-                for (int r = 0; r < R; ++r) {
-                    const double dist = fma(-2.0, dot[r], cq);
-                    if (dist < best[r]) { best[r] = dist; bidx[r] = k0 + j; }
-                }
-            }
-        }
-#pragma unroll
-        for (int r = 0; r < R; ++r) {
-            if (fidx[r] < n) {
-                unsigned long long* srow = (LDS_ACC ? lsum : sums) + (size_t)bidx[r] * d;
-#pragma unroll
-                for (int f = 0; f < D; ++f)
-                    if (f < d) atomicAdd(&srow[f], (unsigned long long)to_fixed(z[r][f], scale));
-                atomicAdd((LDS_ACC ? lcnt : counts) + bidx[r], 1ull);
-            }
-        }
-    }
-    if constexpr (LDS_ACC) {
-        __syncthreads();
-        for (int i = tid; i < k * d; i += kThreads)
-            if (lsum[i]) atomicAdd(&sums[i], lsum[i]);
-        for (int i = tid; i < k; i += kThreads)
-            if (lcnt[i]) atomicAdd(&counts[i], lcnt[i]);
-    }
-}
-
 // centres <- sums / counts (empty clusters keep their centre); shift2 = sum ||delta||^2;
 // done <- shift2 <= tol2.  One workgroup; sums/counts are cleared for the next iteration.
 __global__ __launch_bounds__(1024) void kmeans_update_kernel(unsigned long long* __restrict__ sums,
@@ -385,50 +198,6 @@ __global__ void sum_final_kernel(const double* __restrict__ partial, int nb, dou
         for (int i = 0; i < nb; ++i) t += partial[i];
         *out = t;
     }
-}
-
-template <typename T, int D, int R>
-msm_status launch_accum(msm_ctx* ctx, const T* x, int64_t n, int d, int64_t ld, const double* centers, int k,
-                        const double* mean, const double* stdv, const FitState* st, unsigned long long* sums,
-                        unsigned long long* counts) {
-    const size_t acc_bytes = (size_t)k * (d + 1) * sizeof(unsigned long long);
-    const bool lds_acc = acc_bytes <= 64 * 1024;
-    const size_t budget = lds_acc ? (size_t)(150 * 1024) - acc_bytes : (size_t)kCentreLdsBudget;
-    int tile_k = (int)std::min<size_t>(budget, (size_t)kCentreLdsBudget * 2) / ((D + 1) * (int)sizeof(double));
-    if (tile_k > k) tile_k = k;
-    const size_t lds = (size_t)tile_k * (D + 1) * sizeof(double) + (lds_acc ? acc_bytes : 0);
-    const int64_t frames_per_block = (int64_t)kThreads * R;
-    const int64_t n_blocks = (n + frames_per_block - 1) / frames_per_block;
-    const int per_cu = lds > 80 * 1024 ? 1 : 2;
-    const int grid = (int)std::min<int64_t>(n_blocks, (int64_t)ctx->n_cu * per_cu);
-    auto kern = lds_acc ? kmeans_accum_kernel<T, D, R, true> : kmeans_accum_kernel<T, D, R, false>;
-    if (lds > 48 * 1024)
-        MSM_HIP(ctx, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(kThreads), lds, ctx->stream, x, n, d, ld, centers, k, mean, stdv, tile_k,
-                       st, sums, counts);
-    MSM_CHECK_LAUNCH(ctx);
-    return MSM_OK;
-}
-
-template <typename T>
-msm_status dispatch_accum(msm_ctx* ctx, const T* x, int64_t n, int d, int64_t ld, const double* centers, int k,
-                          const double* mean, const double* stdv, const FitState* st, unsigned long long* sums,
-                          unsigned long long* counts) {
-#define MSM_ACC_CASE(DP, RR) \
-    if (d <= DP) return launch_accum<T, DP, RR>(ctx, x, n, d, ld, centers, k, mean, stdv, st, sums, counts)
-    MSM_ACC_CASE(2, 4);
-    MSM_ACC_CASE(4, 4);
-    MSM_ACC_CASE(6, 4);
-    MSM_ACC_CASE(8, 4);
-    MSM_ACC_CASE(10, 4);
-    MSM_ACC_CASE(12, 4);
-    MSM_ACC_CASE(16, 4);
-    MSM_ACC_CASE(24, 2);
-    MSM_ACC_CASE(32, 2);
-    MSM_ACC_CASE(48, 1);
-    MSM_ACC_CASE(64, 1);
-#undef MSM_ACC_CASE
-    return msm_fail(ctx, MSM_ERR_UNSUPPORTED, "k-means fit: d=%d > 64 not supported yet", d);
 }
 
 // ---------------------------------------------------------------------------
@@ -554,8 +323,10 @@ __global__ __launch_bounds__(kMT, 2) void kmeans_mfma_kernel(
     // The raw coordinates of the NEXT frame group are requested before the tile loop of the
     // current one (clamped addresses, no branches): every wave of a block reaches its loads at the
     // same moment, so without the prefetch the whole CU would sit out each HBM round trip.
-    T raw[NF][KS];
+    constexpr bool kPrefetch = KS <= 16;  // wide frames: the registers go to the frame itself
+    T raw[kPrefetch ? NF : 1][kPrefetch ? KS : 1];
     auto fetch = [&](int64_t unit) {
+        if constexpr (!kPrefetch) return;
 #pragma unroll
         for (int u = 0; u < NF; ++u) {
             int64_t t = unit * frames_per_wave + 16 * u + j16;
@@ -564,7 +335,7 @@ __global__ __launch_bounds__(kMT, 2) void kmeans_mfma_kernel(
 #pragma unroll
             for (int s = 0; s < KS; ++s) {
                 const int f = 4 * s + g;
-                raw[u][s] = row[f < d ? f : d - 1];
+                raw[kPrefetch ? u : 0][kPrefetch ? s : 0] = row[f < d ? f : d - 1];
             }
         }
     };
@@ -602,7 +373,12 @@ __global__ __launch_bounds__(kMT, 2) void kmeans_mfma_kernel(
 #pragma unroll
             for (int s = 0; s < KS; ++s) {
                 const int f = 4 * s + g;
-                double v = (double)raw[u][s];
+                double v;
+                if constexpr (kPrefetch) v = (double)raw[u][s];
+                else {
+                    const int64_t t = fidx[u] < n ? fidx[u] : n - 1;
+                    v = (double)x[t * ld + (f < d ? f : d - 1)];
+                }
                 if (mean) v = (v - mean[f < d ? f : d - 1]) / stdv[f < d ? f : d - 1];
                 if (!(fok[u] && f < d)) v = 0.0;
                 if (fold && s == fold_s && g == fold_g) v = 1.0;
@@ -636,25 +412,25 @@ __global__ __launch_bounds__(kMT, 2) void kmeans_mfma_kernel(
             for (int u = 0; u < NF; ++u) { best[u] = -__builtin_inf(); bpair[u] = 0; }
             for (int jt = 0; jt < n_tiles; jt += 2) {
                 const int jb = min(jt + 1, n_tiles - 1);  // odd tile count: the last tile twice
-                double afa[KS], afb[KS];
-#pragma unroll
-                for (int s = 0; s < KS; ++s) {
-                    afa[s] = cs[jt * TS + s * 64 + lane];
-                    afb[s] = cs[jb * TS + s * 64 + lane];
-                }
                 v4f64 acca[NF], accb[NF];
 #pragma unroll
                 for (int u = 0; u < NF; ++u) { acca[u] = (v4f64){0.0, 0.0, 0.0, 0.0}; accb[u] = acca[u]; }
+                // all of tile a, then all of tile b (the max tree below relies on tile a being
+                // complete when tile b's last MFMA has issued); A fragments stream from LDS
 #pragma unroll
-                for (int s = 0; s < KS; ++s)
-#pragma unroll
-                    for (int u = 0; u < NF; ++u)
-                        acca[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(afa[s], zb[u][s], acca[u], 0, 0, 0);
-#pragma unroll
-                for (int s = 0; s < KS; ++s)
+                for (int s = 0; s < KS; ++s) {
+                    const double afa = cs[jt * TS + s * 64 + lane];
 #pragma unroll
                     for (int u = 0; u < NF; ++u)
-                        accb[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(afb[s], zb[u][s], accb[u], 0, 0, 0);
+                        acca[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(afa, zb[u][s], acca[u], 0, 0, 0);
+                }
+#pragma unroll
+                for (int s = 0; s < KS; ++s) {
+                    const double afb = cs[jb * TS + s * 64 + lane];
+#pragma unroll
+                    for (int u = 0; u < NF; ++u)
+                        accb[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(afb, zb[u][s], accb[u], 0, 0, 0);
+                }
                 if constexpr (!fold) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
@@ -817,43 +593,12 @@ msm_status dispatch_mfma(msm_ctx* ctx, const T* x, int64_t n, int d, int64_t ld,
     MSM_MFMA_CASE(8);
     MSM_MFMA_CASE(12);
     MSM_MFMA_CASE(16);
+    MSM_MFMA_CASE(24);
+    MSM_MFMA_CASE(32);
+    MSM_MFMA_CASE(48);
+    MSM_MFMA_CASE(64);
 #undef MSM_MFMA_CASE
-    return msm_fail(ctx, MSM_ERR_UNSUPPORTED, "k-means: d=%d > 64 not supported yet", d);
-}
-
-template <typename T, int D, int R>
-msm_status launch_assign(msm_ctx* ctx, const T* x, int64_t n, int d, int64_t ld, const double* centers,
-                         int k, const double* mean, const double* stdv, int32_t* labels, double* mindist) {
-    int tile_k = kCentreLdsBudget / ((D + 1) * (int)sizeof(double));
-    if (tile_k > k) tile_k = k;
-    const size_t lds = (size_t)tile_k * (D + 1) * sizeof(double);
-    const int64_t frames_per_block = (int64_t)kThreads * R;
-    const int64_t n_blocks = (n + frames_per_block - 1) / frames_per_block;
-    const int grid = (int)std::min<int64_t>(n_blocks, (int64_t)ctx->n_cu * 2);
-    hipLaunchKernelGGL((kmeans_assign_kernel<T, D, R>), dim3(grid), dim3(kThreads), lds, ctx->stream, x, n, d, ld,
-                       centers, k, mean, stdv, tile_k, labels, mindist);
-    MSM_CHECK_LAUNCH(ctx);
-    return MSM_OK;
-}
-
-template <typename T>
-msm_status dispatch_assign(msm_ctx* ctx, const T* x, int64_t n, int d, int64_t ld, const double* centers,
-                           int k, const double* mean, const double* stdv, int32_t* labels, double* mindist) {
-#define MSM_ASSIGN_CASE(DP, RR) \
-    if (d <= DP) return launch_assign<T, DP, RR>(ctx, x, n, d, ld, centers, k, mean, stdv, labels, mindist)
-    MSM_ASSIGN_CASE(2, 4);
-    MSM_ASSIGN_CASE(4, 4);
-    MSM_ASSIGN_CASE(6, 4);
-    MSM_ASSIGN_CASE(8, 4);
-    MSM_ASSIGN_CASE(10, 4);
-    MSM_ASSIGN_CASE(12, 4);
-    MSM_ASSIGN_CASE(16, 4);
-    MSM_ASSIGN_CASE(24, 2);
-    MSM_ASSIGN_CASE(32, 2);
-    MSM_ASSIGN_CASE(48, 1);
-    MSM_ASSIGN_CASE(64, 1);
-#undef MSM_ASSIGN_CASE
-    return msm_fail(ctx, MSM_ERR_UNSUPPORTED, "msm_kmeans_assign: d=%d > 64 not supported yet", d);
+    return msm_fail(ctx, MSM_ERR_UNSUPPORTED, "k-means: d=%d > 256 not supported", d);
 }
 
 }  // namespace
@@ -883,7 +628,7 @@ msm_status msm_kmeans_fit_begin(msm_ctx* ctx, const void* d_x, msm_dtype dtype, 
                                 const double* d_mean, const double* d_std, int k, uint64_t seed, int init_centers,
                                 double n_total, double tol2, double* d_centers, double* d_state) {
     if (!ctx) return MSM_ERR_INVALID;
-    MSM_REQUIRE(ctx, n >= 1 && d >= 1 && d <= 64 && k >= 1 && ld >= d, "msm_kmeans_fit_begin: bad shape");
+    MSM_REQUIRE(ctx, n >= 1 && d >= 1 && d <= 256 && k >= 1 && ld >= d, "msm_kmeans_fit_begin: bad shape");
     MSM_REQUIRE(ctx, !init_centers || n >= k, "msm_kmeans_fit_begin: fewer frames (%lld) than centres (%d)",
                 (long long)n, k);
     MSM_REQUIRE(ctx, (d_mean == nullptr) == (d_std == nullptr), "msm_kmeans_fit_begin: mean/std must come together");

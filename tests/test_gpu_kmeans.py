@@ -50,6 +50,9 @@ def test_assign_golden_minibatch_branch(engine, golden):
     (20_000, 32, 300, np.float32),
     (5_000, 45, 200, np.float64),     # C4: chignolin distances, un-reduced
     (3_000, 64, 2000, np.float32),    # tiled centres
+    (2_000, 256, 2000, np.float32),   # C5: clustering in the raw 256-d feature space (no TICA dims given)
+    (4_000, 100, 300, np.float64),    # wide frames, d not a multiple of 4
+    (3_000, 128, 700, np.float32),
     (257, 3, 5, np.float64), (1, 1, 1, np.float32)])
 def test_assign_vs_oracle_bit_exact(engine, n, d, k, dtype):
     rng = np.random.default_rng(n + d + k)

@@ -21,7 +21,8 @@ def _fit(engine, X, k, seed=0, max_iter=30, tol2=0.0, mean=None, std=None):
 
 
 @pytest.mark.parametrize("n,d,k,dtype", [(20_000, 4, 100, np.float64), (50_000, 10, 50, np.float32),
-                                          (5_000, 2, 8, np.float64), (3_000, 24, 40, np.float32)])
+                                          (5_000, 2, 8, np.float64), (3_000, 24, 40, np.float32),
+                                          (3_000, 256, 150, np.float32)])  # C5 width: global-atomic member sums
 def test_fit_bit_exact_vs_restated_lloyd(engine, n, d, k, dtype):
     X = _gen.correlated_series(n, d, seed=n % 13).astype(dtype)
     got, st, _ = _fit(engine, X, k, seed=7, max_iter=6)
