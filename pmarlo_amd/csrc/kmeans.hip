@@ -227,7 +227,9 @@ __global__ void sum_final_kernel(const double* __restrict__ partial, int nb, dou
 typedef double v4f64 __attribute__((ext_vector_type(4)));
 // 8 waves share one LDS centre tile (+ the fixed-point accumulators): two waves per SIMD even
 // when tile + accumulators take ~100 KB.
-constexpr int kMT = 512;
+// workgroup size of the matrix-core kernel: 16 waves (4 per SIMD, <= 128 VGPRs, two frame groups
+// per wave) while the frame fits 16 features, 8 waves (<= 256 VGPRs) for wider frames
+constexpr int kMTNarrow = 1024, kMTWide = 512;
 
 // one v_max_f64: fmax() would first canonicalise both operands (two more VALU ops each);
 // NaNs lose against numbers here too.  The caller pads the MFMA -> VALU hazard itself.
@@ -255,8 +257,8 @@ __device__ unsigned long long g_km_stamps[8];
 #define KSTAMP_FLUSH
 #endif
 
-template <typename T, int KS, int NF, bool ACCUM, bool FOLD>
-__global__ __launch_bounds__(kMT, 2) void kmeans_mfma_kernel(
+template <typename T, int KS, int NF, int kMT, bool ACCUM, bool FOLD>
+__global__ __launch_bounds__(kMT, kMT == 1024 ? 4 : 2) void kmeans_mfma_kernel(
     const T* __restrict__ x, int64_t n, int d, int64_t ld, const double* __restrict__ centers, int k,
     const double* __restrict__ mean, const double* __restrict__ stdv, int tile_k /* multiple of 16 */,
     int32_t* __restrict__ labels, double* __restrict__ mindist, const FitState* __restrict__ st,
@@ -323,7 +325,9 @@ __global__ __launch_bounds__(kMT, 2) void kmeans_mfma_kernel(
     // The raw coordinates of the NEXT frame group are requested before the tile loop of the
     // current one (clamped addresses, no branches): every wave of a block reaches its loads at the
     // same moment, so without the prefetch the whole CU would sit out each HBM round trip.
-    constexpr bool kPrefetch = KS <= 16;  // wide frames: the registers go to the frame itself
+    // prefetch only in the 8-wave configuration with registers to spare (4 waves per SIMD hide
+    // the load latency by themselves; wide frames need the registers for the frame)
+    constexpr bool kPrefetch = KS > 4 && KS <= 16;
     T raw[kPrefetch ? NF : 1][kPrefetch ? KS : 1];
     auto fetch = [&](int64_t unit) {
         if constexpr (!kPrefetch) return;
@@ -556,7 +560,8 @@ template <typename T, int KS, bool ACCUM>
 msm_status launch_mfma(msm_ctx* ctx, const T* x, int64_t n, int d, int64_t ld, const double* centers, int k,
                        const double* mean, const double* stdv, int32_t* labels, double* mindist, const FitState* st,
                        unsigned long long* sums, unsigned long long* counts) {
-    constexpr int NF = KS <= 4 ? 4 : (KS <= 8 ? 2 : 1);
+    constexpr int NF = KS <= 8 ? 2 : 1;
+    constexpr int kMT = KS <= 4 ? kMTNarrow : kMTWide;
     constexpr int TS = KS * 64 + 1;  // doubles per 16-centre tile (see the kernel)
     const size_t acc_bytes = ACCUM ? (size_t)k * (d + 1) * sizeof(unsigned long long) : 0;
     const int lds_acc = ACCUM && acc_bytes <= 64 * 1024;
@@ -569,7 +574,7 @@ msm_status launch_mfma(msm_ctx* ctx, const T* x, int64_t n, int d, int64_t ld, c
     const int64_t n_units = (n + 16 * NF - 1) / (16 * NF);
     const int waves = kMT / 64;
     const int grid = (int)std::min<int64_t>((n_units + waves - 1) / waves, (int64_t)ctx->n_cu);
-    auto kern = (d & 3) != 0 ? kmeans_mfma_kernel<T, KS, NF, ACCUM, true> : kmeans_mfma_kernel<T, KS, NF, ACCUM, false>;
+    auto kern = (d & 3) != 0 ? kmeans_mfma_kernel<T, KS, NF, kMT, ACCUM, true> : kmeans_mfma_kernel<T, KS, NF, kMT, ACCUM, false>;
     if (lds > 48 * 1024)
         MSM_HIP(ctx, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(kern, dim3(grid), dim3(kMT), lds, ctx->stream, x, n, d, ld, centers, k, mean, stdv, tile_k,
