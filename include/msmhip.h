@@ -363,6 +363,26 @@ msm_status msm_spectrum(msm_ctx* ctx, const double* d_T, int64_t t_stride, int l
                         double* d_change, int32_t* d_status, int n_its, const double* d_lags,
                         double* d_its_eig, double* d_its_ts);
 
+/* ---- Chapman-Kolmogorov test ---------------------------------------------
+ * msm_gemm_f64: C (m x n) = A (m x k) . B (k x n), row-major fp64 on the matrix cores; every
+ * output element is the ascending-k FMA chain from +0 (bit-reproducible).  C must not alias
+ * A or B.  Building block of the matrix powers below.
+ *
+ * msm_ck_test replaces the numerics of ck_error / _multinomial_rms_se / decide_ck
+ * (S/validation/ck_rule.py:36-63, 71-117) and of _ck_on_trajs (S/markov_state_model/
+ * ck_runner.py:155-176): for every factor f = h_factors[i]
+ *   d_mse[i]   = mean((T1^f - Tk[i])^2)                         (RMS error = sqrt of it)
+ *   d_noise[i] = sqrt(mean_i(sum_j p_ij (1 - p_ij) / N_i / n)),  p = Tk[i], N = row counts of
+ *                the lag-f*tau count matrix (N_i <= 0 or non-finite -> 1); skipped when
+ *                d_rowcounts / d_noise are NULL
+ * d_T1 f64 [n, ld1]; d_Tk f64 [n_factors][tk_stride] with row stride ldk; d_rowcounts f64
+ * [n_factors][rc_stride].  T1^f is formed by f-1 right-multiplications with T1. */
+msm_status msm_gemm_f64(msm_ctx* ctx, int m, int n, int k, const double* d_A, int64_t lda,
+                        const double* d_B, int64_t ldb, double* d_C, int64_t ldc);
+msm_status msm_ck_test(msm_ctx* ctx, const double* d_T1, int64_t ld1, const double* d_Tk,
+                       int64_t tk_stride, int64_t ldk, int n, const int32_t* h_factors, int n_factors,
+                       const double* d_rowcounts, int64_t rc_stride, double* d_mse, double* d_noise);
+
 #ifdef __cplusplus
 }
 #endif

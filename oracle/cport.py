@@ -40,6 +40,8 @@ def _load():
         _lib.oracle_kmeans_assign.argtypes = [
             C.c_void_p, C.c_int64, C.c_int, C.c_int64, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
             C.c_void_p, C.c_void_p]
+        _lib.oracle_gemm_fma.restype = None
+        _lib.oracle_gemm_fma.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int]
         _lib.oracle_kmeans_fit.restype = C.c_int
         _lib.oracle_kmeans_fit.argtypes = [C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_uint64, C.c_int, C.c_double,
                                            C.c_double, C.c_void_p, C.c_void_p]
@@ -108,3 +110,15 @@ def kmeans_fit(xz, k, seed=0, max_iter=50, tol2=0.0, n_total=None):
     it = lib.oracle_kmeans_fit(xz.ctypes.data, n, d, k, int(seed), int(max_iter), float(tol2),
                                float(n if n_total is None else n_total), centers.ctypes.data, C.byref(scale))
     return centers, int(it), float(scale.value)
+
+
+def gemm_fma(A, B):
+    """A . B with every element the ascending-k fma chain from +0 (bit-level mirror of msm_gemm_f64)."""
+    A = np.ascontiguousarray(A, np.float64)
+    B = np.ascontiguousarray(B, np.float64)
+    m, k = A.shape
+    k2, n = B.shape
+    assert k == k2
+    Cm = np.empty((m, n), np.float64)
+    _load().oracle_gemm_fma(A.ctypes.data, B.ctypes.data, Cm.ctypes.data, m, n, k)
+    return Cm

@@ -408,3 +408,109 @@ def trig_expand_periodic(X, periodic):
             cols.append(X[:, j])
             mapping.append(j)
     return (np.vstack(cols).T if cols else X), np.asarray(mapping, dtype=int)
+
+
+# ---------------------------------------------------------------------------
+# Chapman-Kolmogorov test (S/validation/ck_rule.py:36-117, S/markov_state_model/ck_runner.py:70-83,
+# 155-176, 240-270).  Pinned by tests/golden/ck.npz (ck_rule imported from the reference).
+# ---------------------------------------------------------------------------
+def ck_error(P_tau, P_k_tau, k):
+    """RMS of matrix_power(P_tau, k) - P_k_tau (ck_rule.py:36-47)."""
+    P_tau = np.asarray(P_tau, float)
+    P_k_tau = np.asarray(P_k_tau, float)
+    if P_tau.shape != P_k_tau.shape or P_tau.shape[0] != P_tau.shape[1]:
+        raise ValueError("P_tau and P_k_tau must be square matrices of identical shape.")
+    d = np.linalg.matrix_power(P_tau, int(k)) - P_k_tau
+    return float(np.sqrt(np.mean(d * d)))
+
+
+def multinomial_rms_se(P, counts):
+    """ck_rule.py:50-63: sqrt(mean_i(sum_j p_ij (1 - p_ij) / N_i / n)), bad N_i -> 1."""
+    P = np.asarray(P, float)
+    counts = np.asarray(counts, float)
+    n = P.shape[0]
+    if counts.shape[0] != n:
+        raise ValueError("counts length must equal number of states.")
+    N = np.where(np.isfinite(counts) & (counts > 0.0), counts, 1.0)
+    rows = (P * (1.0 - P)).sum(axis=1) / N / n
+    return float(np.sqrt(np.mean(rows)))
+
+
+def decide_ck(P_taus, P_ktaus, row_counts_by_lag, *, mode="ess_adjusted", absolute=0.15, min_pass_fraction=0.8,
+              per_lag_cap=0.35, k_steps=(2, 3, 4), sigma_mult=3.0):
+    """ck_rule.py:71-117 -> dict(pass_fraction, per_lag, passed)."""
+    per_lag, total, passes = {}, 0, 0
+    for k in k_steps:
+        if k not in P_taus or k not in P_ktaus or k not in row_counts_by_lag:
+            continue
+        total += 1
+        err = ck_error(P_taus[k], P_ktaus[k], k)
+        if mode == "absolute":
+            thr, noise = absolute, float("nan")
+        elif mode == "ess_adjusted":
+            noise = multinomial_rms_se(P_ktaus[k], row_counts_by_lag[k])
+            thr = float(min(per_lag_cap, sigma_mult * noise))
+        else:
+            raise ValueError(f"Unknown CK mode: {mode}")
+        ok = err <= thr
+        passes += int(ok)
+        per_lag[k] = {"error": err, "threshold": thr, "noise_rms": noise, "pass": float(ok)}
+    frac = passes / total if total else 0.0
+    return {"pass_fraction": frac, "per_lag": per_lag, "passed": frac >= min_pass_fraction}
+
+
+def ck_micro(dtrajs, lag_time, factors=(2, 3, 4, 5), min_trans=50, top_n_micro=50):
+    """Microstate branch of run_ck (ck_runner.py:135-153 preprocessing, :240-270 selection, :155-176
+    test): states with lag-1 in/out counts > 0 are kept and renumbered (frames in other states are
+    DROPPED from the sequences, as the reference does), the top_n_micro most populated (lag tau
+    counts) are selected the same way, then mse[f] = mean((T1^f - T_f)^2) for every factor whose
+    lag-f*tau count rows all reach min_trans."""
+    def count(trajs, n, lag):
+        C = np.zeros((n, n))
+        for t in trajs:
+            t = np.asarray(t, dtype=np.int64)
+            if t.size <= lag:
+                continue
+            a, b = t[:-lag], t[lag:]
+            ok = (a >= 0) & (b >= 0) & (a < n) & (b < n)
+            np.add.at(C, (a[ok], b[ok]), 1.0)
+        return C
+
+    def rownorm(C):
+        rs = C.sum(axis=1, keepdims=True)
+        rs[rs == 0] = 1.0
+        return C / rs
+
+    def relabel(trajs, keep):
+        lut = -np.ones(int(max(int(np.max(t)) for t in trajs if len(t)) + 1), dtype=np.int64)
+        lut[keep] = np.arange(len(keep))
+        return [lut[np.asarray(t, dtype=np.int64)][lut[np.asarray(t, dtype=np.int64)] >= 0] for t in trajs]
+
+    out = {"mse": {}, "insufficient_k": [int(f) for f in factors], "mode": "none"}
+    n_states = int(max(int(np.max(t)) for t in dtrajs) + 1)
+    C1 = count(dtrajs, n_states, 1)
+    active = np.where(C1.sum(axis=1) + C1.sum(axis=0) > 0)[0]
+    if active.size == 0:
+        return out
+    trajs = relabel(dtrajs, active)
+    Ctau = count(trajs, active.size, lag_time)
+    pops = Ctau.sum(axis=1) + Ctau.sum(axis=0)
+    if np.count_nonzero(pops) == 0:
+        return out
+    top = np.argsort(-pops, kind="stable")[: min(int(top_n_micro), pops.size)]
+    micro = relabel(trajs, top)
+    n_sel = top.size
+    Csel = count(micro, n_sel, lag_time)
+    if np.any(Csel.sum(axis=1) < min_trans):
+        return out
+    T1 = rownorm(Csel)
+    for f in factors:
+        Ck = count(micro, n_sel, lag_time * int(f))
+        if np.any(Ck.sum(axis=1) < min_trans):
+            continue
+        d = np.linalg.matrix_power(T1, int(f)) - rownorm(Ck)
+        out["mse"][int(f)] = float(np.mean(d * d))
+        out["insufficient_k"].remove(int(f))
+    out["mode"] = "micro"
+    out["selected"] = active[top]
+    return out

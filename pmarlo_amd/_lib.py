@@ -79,6 +79,8 @@ _PROTOTYPES: dict[str, tuple] = {
     "msm_spectrum_workspace_bytes": (_sz, [_i32, _i32, _i32]),
     "msm_spectrum": (_i32, [_vp, _vp, _i64, _i32, _vp, _i32, _i32, _i32, _i32, _i32, C.c_uint64, _i32, _vp, _vp, _vp,
                             _i64, _vp, _vp, _i32, _vp, _vp, _vp]),
+    "msm_gemm_f64": (_i32, [_vp, _i32, _i32, _i32, _vp, _i64, _vp, _i64, _vp, _i64]),
+    "msm_ck_test": (_i32, [_vp, _vp, _i64, _vp, _i64, _i64, _i32, _vp, _i32, _vp, _i64, _vp, _vp]),
 }
 
 DECLARED_SYMBOLS = tuple(_PROTOTYPES)

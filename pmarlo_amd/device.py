@@ -79,6 +79,14 @@ class DeviceArray:
                   self.engine.handle)
         return self
 
+    def copy_from(self, src: "DeviceArray") -> "DeviceArray":
+        """Device-to-device copy of `src` (same byte count) into this array."""
+        if src.nbytes != self.nbytes:
+            raise ValueError(f"size mismatch: {self.nbytes} vs {src.nbytes} bytes")
+        if self.nbytes:
+            check(lib.msm_memcpy_d2d(self.engine.handle, self.ptr, src.ptr, self.nbytes), self.engine.handle)
+        return self
+
     def zero_(self) -> "DeviceArray":
         check(lib.msm_memset(self.engine.handle, self.ptr, 0, self.nbytes), self.engine.handle)
         return self
@@ -467,6 +475,31 @@ class Engine:
         check(lib.msm_embed_full(self.handle, T_active.ptr, pi_active.ptr if pi_active is not None else None,
                                  inv_map.ptr, k, T_full.ptr, pi_full.ptr), self.handle)
         return T_full, pi_full
+
+    def gemm(self, A: DeviceArray, B: DeviceArray, out: DeviceArray | None = None) -> DeviceArray:
+        """C = A . B (fp64, matrix cores; ascending-k FMA chain per element)."""
+        m, k = A.shape
+        k2, n = B.shape
+        if k != k2:
+            raise ValueError(f"gemm: inner dimensions differ ({k} vs {k2})")
+        C = out if out is not None else self.empty((m, n), np.float64)
+        check(lib.msm_gemm_f64(self.handle, m, n, k, A.ptr, k, B.ptr, n, C.ptr, n), self.handle)
+        return C
+
+    def ck_test(self, T1: DeviceArray, Tk: DeviceArray, factors, rowcounts: DeviceArray | None = None):
+        """mse[i] = mean((T1^f_i - Tk[i])^2) and, with row counts [F, n], the multinomial noise RMS
+        of Tk[i] (validation/ck_rule.py:36-63).  T1 [n, n]; Tk [F, n, n]."""
+        n = T1.shape[0]
+        fac = np.ascontiguousarray(factors, dtype=np.int32)
+        F = int(fac.size)
+        if tuple(Tk.shape) != (F, n, n):
+            raise ValueError(f"ck_test: Tk must have shape ({F}, {n}, {n}), got {tuple(Tk.shape)}")
+        mse = self.empty((max(F, 1),), np.float64)
+        noise = self.empty((max(F, 1),), np.float64) if rowcounts is not None else None
+        check(lib.msm_ck_test(self.handle, T1.ptr, n, Tk.ptr, n * n, n, n, fac.ctypes.data, F,
+                              rowcounts.ptr if rowcounts is not None else None, n, mse.ptr,
+                              noise.ptr if noise is not None else None), self.handle)
+        return mse.to_host()[:F], (noise.to_host()[:F] if noise is not None else None)
 
     def spectrum(self, T: DeviceArray, *, n: DeviceArray | None = None, n_its: int = 0, lags=None,
                  p: int | None = None, want_pi: bool = True, tol: float = 1e-9, n_iter: int = 24,

@@ -1,4 +1,5 @@
 """pmarlo.markov_state_model operators on the MI355X engine."""
+from .ck import CKRunResult, run_ck  # noqa: F401
 from .clustering import ClusteringResult, cluster_microstates  # noqa: F401
 from .estimation import (build_msm, compute_free_energies, count_transitions,  # noqa: F401
                          ensure_connected_counts, finalize_transition_and_stationary)

@@ -9,8 +9,8 @@ coordinates parsed from the reference's data/*.pdb) or the output of a reference
 function on that input.  No reference source text is stored.  The functions
 exercised are the importable half of the path:
 pmarlo.analysis.{discretize,counting,debug_export,msm}, reduction._preprocess,
-trainer_api._estimate_top_eigenvalues, utils.safe_timescales and the torch
-feature extractor.
+trainer_api._estimate_top_eigenvalues, utils.safe_timescales, validation.ck_rule and the
+torch feature extractor.
 """
 
 from __future__ import annotations
@@ -255,7 +255,43 @@ def golden_featurizer():
     np.savez_compressed(OUT / "featurizer.npz", **out)
 
 
+def golden_ck():
+    """validation/ck_rule.py: ck_error, _multinomial_rms_se, decide_ck (both modes) on seeded
+    row-stochastic matrices: a metastable chain whose lag-k matrices are its exact powers plus
+    sampling noise, so some factors pass and some fail."""
+    from pmarlo.validation import ck_rule
+
+    rng = np.random.default_rng(77)
+    n = 12
+    base = rng.random((n, n)) * 0.02
+    for b in range(3):
+        base[4 * b:4 * b + 4, 4 * b:4 * b + 4] += rng.random((4, 4)) + 0.5
+    P = base / base.sum(axis=1, keepdims=True)
+    out = {"P": P}
+    P_taus, P_ktaus, rows = {}, {}, {}
+    for k, noise in ((2, 0.0), (3, 0.002), (4, 0.2), (5, 0.01)):
+        Pk = np.linalg.matrix_power(P, k) + noise * rng.random((n, n))
+        Pk /= Pk.sum(axis=1, keepdims=True)
+        counts = rng.integers(40, 4000, size=n).astype(float)
+        if k == 3:
+            counts[2] = 0.0          # exercises the N_i <= 0 -> 1 rule
+        P_taus[k], P_ktaus[k], rows[k] = P, Pk, counts
+        out[f"Pk_{k}"] = Pk
+        out[f"rows_{k}"] = counts
+        out[f"err_{k}"] = ck_rule.ck_error(P, Pk, k)
+        out[f"se_{k}"] = ck_rule._multinomial_rms_se(Pk, counts)
+    for mode in ("ess_adjusted", "absolute"):
+        cfg = ck_rule.CKConfig(mode=mode, k_steps=(2, 3, 4, 5))
+        dec = ck_rule.decide_ck(P_taus, P_ktaus, rows, cfg)
+        out[f"{mode}_pass_fraction"] = dec.pass_fraction
+        out[f"{mode}_passed"] = dec.passed
+        out[f"{mode}_per_lag"] = np.array([[k, v["error"], v["threshold"], v["noise_rms"], v["pass"]]
+                                           for k, v in sorted(dec.per_lag.items())])
+    np.savez_compressed(OUT / "ck.npz", **out)
+
+
 if __name__ == "__main__":
+    golden_ck()
     golden_counts()
     golden_preprocess_tica()
     golden_kmeans()

@@ -1,0 +1,91 @@
+"""Chapman-Kolmogorov test on the GPU (msm_gemm_f64, msm_ck_test) against the oracle and the
+golden vectors made by importing the reference's validation/ck_rule.py.
+
+Tolerances: the GEMM is an ascending-k FMA chain per element -> bit-exact against the same chain
+on the CPU; against numpy's blocked matmul / matrix_power (squaring) 1e-13 relative."""
+import numpy as np
+import pytest
+
+from oracle import cport, npport
+from pmarlo_amd.markov_state_model import run_ck
+from pmarlo_amd.validation import CKConfig, ck_error, decide_ck
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("m,n,k", [(16, 16, 4), (33, 17, 50), (1, 1, 1), (200, 200, 200), (500, 500, 500), (7, 300, 3)])
+def test_gemm(engine, m, n, k):
+    rng = np.random.default_rng(m * 7 + n * 3 + k)
+    A, B = rng.normal(size=(m, k)), rng.normal(size=(k, n))
+    C = engine.gemm(engine.to_device(A), engine.to_device(B)).to_host()
+    np.testing.assert_allclose(C, A @ B, rtol=1e-13, atol=1e-13 * np.abs(A).max() * np.abs(B).max() * k)
+    np.testing.assert_array_equal(C, cport.gemm_fma(A, B))   # same FMA chain, bit for bit
+
+
+def test_gemm_rejects_aliasing_and_bad_shapes(engine):
+    A = engine.to_device(np.eye(4))
+    with pytest.raises(ValueError):
+        engine.gemm(A, A, out=A)
+    with pytest.raises(ValueError):
+        engine.gemm(A, engine.to_device(np.zeros((3, 4))))
+
+
+def test_ck_rule_against_reference_golden(golden):
+    g = golden("ck.npz")
+    P = g["P"]
+    Pt, Pk, rows = {}, {}, {}
+    for k in (2, 3, 4, 5):
+        Pt[k], Pk[k], rows[k] = P, g[f"Pk_{k}"], g[f"rows_{k}"]
+        np.testing.assert_allclose(ck_error(P, Pk[k], k), float(g[f"err_{k}"]), rtol=1e-11, atol=1e-15)
+    for mode in ("ess_adjusted", "absolute"):
+        dec = decide_ck(Pt, Pk, rows, CKConfig(mode=mode, k_steps=(2, 3, 4, 5)))
+        assert dec.pass_fraction == float(g[f"{mode}_pass_fraction"])
+        assert dec.passed == bool(g[f"{mode}_passed"])
+        got = np.array([[k, v["error"], v["threshold"], v["noise_rms"], v["pass"]] for k, v in sorted(dec.per_lag.items())])
+        np.testing.assert_allclose(got, g[f"{mode}_per_lag"], rtol=1e-11, atol=1e-15, equal_nan=True)
+        assert ("PASSED" in dec.reason) == dec.passed
+    with pytest.raises(ValueError):
+        ck_error(P, P[:5, :5], 2)
+
+
+def _markov_dtrajs(k, n, seed, n_traj=3):
+    rng = np.random.default_rng(seed)
+    T = rng.random((k, k)) * 0.05
+    for b in range(0, k, 5):
+        T[b:b + 5, b:b + 5] += rng.random((min(5, k - b), min(5, k - b))) + 0.3
+    T /= T.sum(axis=1, keepdims=True)
+    cdf = np.cumsum(T, axis=1)
+    out = []
+    for t in range(n_traj):
+        u = rng.random(n)
+        s = np.empty(n, dtype=np.int64)
+        s[0] = rng.integers(k)
+        for i in range(1, n):
+            s[i] = min(k - 1, int(np.searchsorted(cdf[s[i - 1]], u[i])))
+        out.append(s + 3 * (t == 0))     # trajectory 0 uses a shifted label range: unused ids 0..2
+    return out
+
+
+@pytest.mark.parametrize("k,n,lag,top_n", [(20, 30_000, 2, 50), (60, 60_000, 1, 25)])
+def test_run_ck_micro_vs_oracle(k, n, lag, top_n):
+    dtrajs = _markov_dtrajs(k, n, seed=k)
+    want = npport.ck_micro(dtrajs, lag, factors=(2, 3, 4, 5), min_trans=50, top_n_micro=top_n)
+    got = run_ck(dtrajs, lag, min_trans=50, top_n_micro=top_n, factors=(2, 3, 4, 5))
+    assert got.mode == want["mode"] == "micro"
+    assert sorted(got.mse) == sorted(want["mse"]) and got.insufficient_k == want["insufficient_k"]
+    np.testing.assert_array_equal(got.selected_states, want["selected"])
+    for f, v in want["mse"].items():
+        np.testing.assert_allclose(got.mse[f], v, rtol=1e-10)
+    assert got.max_error == pytest.approx(np.sqrt(max(want["mse"].values())), rel=1e-10)
+
+
+def test_run_ck_insufficient_and_errors():
+    dtrajs = _markov_dtrajs(10, 400, seed=1, n_traj=1)
+    res = run_ck(dtrajs, 5, min_trans=50, factors=(2, 30))
+    assert 30 in res.insufficient_k
+    with pytest.raises(ValueError):
+        run_ck([], 1)
+    with pytest.raises(ValueError):
+        run_ck(dtrajs, 0)
+    with pytest.raises(ValueError):
+        run_ck(dtrajs, 1, factors=(1,))
