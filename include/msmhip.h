@@ -383,6 +383,37 @@ msm_status msm_ck_test(msm_ctx* ctx, const double* d_T1, int64_t ld1, const doub
                        int64_t tk_stride, int64_t ldk, int n, const int32_t* h_factors, int n_factors,
                        const double* d_rowcounts, int64_t rc_stride, double* d_mse, double* d_noise);
 
+/* ---- free-energy surfaces (S/analysis/fes.py) -----------------------------
+ * msm_weighted_stats: d_out6 = {sum w, sum w^2, weighted mean, weighted variance (around that
+ *   mean, / sum w), min, max} of the strided coordinate x[i * stride]; d_w NULL = unit weights
+ *   (np.average twice, _compute_bandwidth :142-173; data range of np.histogram2d).
+ * msm_hist2d: np.histogram2d(x, y, bins=[nx, ny], weights=w) on the given edges (:241-249):
+ *   bin = searchsorted(edges, v, 'right') - 1, last edge inclusive, values outside or NaN
+ *   dropped.  d_hist f64 [nx, ny].  Weighted sums run in 2^e fixed point (e from n * w_absmax,
+ *   w_absmax >= max |w|): independent of scheduling, exact to 2^-e per frame.
+ * msm_smooth_sparse_bins: bins < min_count are raised to max(mean of the 8 neighbours with
+ *   replicated edges, min_count) when that mean is > 0 (:270-292); d_out != d_hist;
+ *   *d_n_smoothed = number of changed bins.  msm_scale_to_total rescales to a given sum
+ *   (the reference restores the raw total only when something was smoothed, :254-258).
+ * msm_fes_finalize: F = -kT ln(h / sum h) - min (:570-599).  *d_status: 0 ok, bit 0 non-finite
+ *   entry, bit 1 total <= 0, bit 2 entry <= 0 (the reference raises for each).
+ * msm_kde2d: density[i][j] = 1/(2 pi bw_x bw_y) sum_k w_k w_scale exp(-((xc_i - x_k)/bw_x)^2/2)
+ *   exp(-((yc_j - y_k)/bw_y)^2/2) on the matrix cores (:176-238); d_w NULL = all weights
+ *   w_scale. */
+msm_status msm_weighted_stats(msm_ctx* ctx, const double* d_x, int64_t stride, int64_t n,
+                              const double* d_w, double* d_out6);
+msm_status msm_hist2d(msm_ctx* ctx, const double* d_x, int64_t sx, const double* d_y, int64_t sy,
+                      int64_t n, const double* d_w, double w_absmax, const double* d_xedges, int nx,
+                      const double* d_yedges, int ny, double* d_hist);
+msm_status msm_smooth_sparse_bins(msm_ctx* ctx, const double* d_hist, int nx, int ny,
+                                  double min_count, double* d_out, int32_t* d_n_smoothed);
+msm_status msm_scale_to_total(msm_ctx* ctx, double* d_v, int n, double total);
+msm_status msm_fes_finalize(msm_ctx* ctx, const double* d_hist, int n_cells, double kT,
+                            double* d_F, int32_t* d_status);
+msm_status msm_kde2d(msm_ctx* ctx, const double* d_x, int64_t sx, const double* d_y, int64_t sy,
+                     int64_t n, const double* d_w, double w_scale, const double* d_xcenters, int nx,
+                     const double* d_ycenters, int ny, double bw_x, double bw_y, double* d_density);
+
 #ifdef __cplusplus
 }
 #endif

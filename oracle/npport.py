@@ -514,3 +514,121 @@ def ck_micro(dtrajs, lag_time, factors=(2, 3, 4, 5), min_trans=50, top_n_micro=5
     out["mode"] = "micro"
     out["selected"] = active[top]
     return out
+
+
+# ---------------------------------------------------------------------------
+# Weighted free-energy surface (S/analysis/fes.py:20-88, 91-114, 142-292, 411-599).
+# Pinned by tests/golden/fes.npz (compute_weighted_fes imported from the reference).
+# ---------------------------------------------------------------------------
+KB_KJ_PER_MOL = 0.00831446261815324  # S/constants.py:16
+
+
+def fes_select_components(coords, n_components=2):
+    """fes.py:20-88: the n_components non-constant columns of highest (population) variance."""
+    coords = np.asarray(coords)
+    if coords.ndim != 2:
+        raise ValueError(f"Expected 2D coordinate array, got shape {coords.shape}")
+    if coords.shape[1] < n_components:
+        raise ValueError(f"Coordinate array has {coords.shape[1]} dimensions, need {n_components}")
+    var = np.var(coords, axis=0)
+    idx = np.where(var > 0)[0]
+    if idx.size < n_components:
+        raise ValueError("FES component selection requires at least "
+                         f"{n_components} non-constant CV columns; found {idx.size}")
+    order = idx[np.argsort(var[idx])[::-1]][:n_components].tolist()
+    return coords[:, order], order
+
+
+def fes_normalise_weights(n_frames, weights):
+    """fes.py:91-114 -> (normalised weights, total, effective sample size)."""
+    if weights is None:
+        return np.full(n_frames, 1.0 / n_frames), float(n_frames), float(n_frames)
+    w = np.asarray(weights, dtype=np.float64).reshape(-1)
+    if w.shape[0] != n_frames:
+        raise ValueError("Frame weights must match number of frames")
+    if np.any(w < 0.0) or not np.all(np.isfinite(w)):
+        raise ValueError("Frame weights must be finite and non-negative")
+    total = float(np.sum(w))
+    if total <= 0.0:
+        raise ValueError("Frame weights must sum to a positive value")
+    return w / total, total, total ** 2 / float(np.sum(w ** 2))
+
+
+def fes_bandwidth(coord, w_norm, ess, selector):
+    """fes.py:142-173 (d = 2)."""
+    if isinstance(selector, (int, float)):
+        if selector <= 0:
+            raise ValueError("Bandwidth must be positive")
+        return float(selector)
+    mean = float(np.average(coord, weights=w_norm))
+    var = float(np.average((coord - mean) ** 2, weights=w_norm))
+    if var <= 0.0:
+        raise ValueError("Coordinate variance must be positive to compute bandwidth")
+    n_eff = max(ess, 1.0)
+    sel = str(selector).lower()
+    if sel == "scott":
+        factor = n_eff ** (-1.0 / 6.0)
+    elif sel == "silverman":
+        factor = (n_eff * 4.0 / 4.0) ** (-1.0 / 6.0)
+    else:
+        raise ValueError("Bandwidth must be 'scott', 'silverman', or a positive float")
+    return float(np.sqrt(var) * factor)
+
+
+def fes_smooth_sparse_bins(hist, min_count):
+    """fes.py:270-292 with the 3 x 3 'nearest' filter written out."""
+    mask = hist < float(min_count)
+    if not np.any(mask):
+        return hist, 0
+    p = np.pad(hist, 1, mode="edge")
+    nx, ny = hist.shape
+    tot = sum(p[1 + di:1 + di + nx, 1 + dj:1 + dj + ny] for di in (-1, 0, 1) for dj in (-1, 0, 1))
+    nm = (tot - hist) / 8.0
+    targets = np.maximum(nm, float(min_count))
+    upd = mask & (nm > 0.0) & (targets > hist)
+    out = hist.copy()
+    out[upd] = targets[upd]
+    return out, int(np.count_nonzero(upd))
+
+
+def fes_free_energy(hist, temperature_K):
+    """fes.py:570-599."""
+    hist = np.asarray(hist, float)
+    total = float(np.sum(hist))
+    if not np.all(np.isfinite(hist)) or not np.isfinite(total) or total <= 0 or np.any(hist <= 0):
+        raise ValueError("Histogram entries must be strictly positive and finite for FES")
+    F = -(KB_KJ_PER_MOL * float(temperature_K)) * np.log(hist / total)
+    return F - np.min(F)
+
+
+def weighted_fes(X, *, weights=None, bins=64, temperature_K=300.0, method="kde", bandwidth="scott",
+                 min_count_per_bin=1):
+    """compute_weighted_fes on a plain (N, d) array (fes.py:411-453 without the dataset plumbing)."""
+    coords, sel = fes_select_components(np.asarray(X, float), 2)
+    cx, cy = coords[:, 0], coords[:, 1]
+    w = None if weights is None else np.asarray(weights, np.float64).reshape(-1)
+    meta = {"selected_components": sel}
+    if method == "kde":
+        w_norm, total, ess = fes_normalise_weights(cx.shape[0], w)
+        nx, ny = (int(bins), int(bins)) if np.isscalar(bins) else (int(bins[0]), int(bins[1]))
+        bwx, bwy = fes_bandwidth(cx, w_norm, ess, bandwidth), fes_bandwidth(cy, w_norm, ess, bandwidth)
+        xe = np.linspace(cx.min() - 3.0 * bwx, cx.max() + 3.0 * bwx, nx + 1)
+        ye = np.linspace(cy.min() - 3.0 * bwy, cy.max() + 3.0 * bwy, ny + 1)
+        xc, yc = 0.5 * (xe[:-1] + xe[1:]), 0.5 * (ye[:-1] + ye[1:])
+        ex = np.exp(-0.5 * ((xc[:, None] - cx[None, :]) / bwx) ** 2)
+        ey = np.exp(-0.5 * ((yc[:, None] - cy[None, :]) / bwy) ** 2)
+        hist = np.einsum("ik,jk,k->ij", ex, ey, w_norm) / (2.0 * np.pi * bwx * bwy)
+        meta.update(bw_x=bwx, bw_y=bwy, ess=ess, total_weight=total)
+    elif method == "grid":
+        hist, xe, ye = np.histogram2d(cx, cy, bins=bins, weights=w)
+        raw_total = float(hist.sum())
+        smoothed = 0
+        if min_count_per_bin > 0:
+            hist, smoothed = fes_smooth_sparse_bins(hist, int(min_count_per_bin))
+            if smoothed > 0 and raw_total > 0 and hist.sum() > 0:
+                hist = hist * (raw_total / float(hist.sum()))
+        meta["smoothed_bins"] = smoothed
+    else:
+        raise ValueError("FES method must be either 'kde' or 'grid'")
+    return {"histogram": hist, "xedges": xe, "yedges": ye, "free_energy": fes_free_energy(hist, temperature_K),
+            "metadata": meta}

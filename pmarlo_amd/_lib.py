@@ -80,6 +80,12 @@ _PROTOTYPES: dict[str, tuple] = {
     "msm_spectrum": (_i32, [_vp, _vp, _i64, _i32, _vp, _i32, _i32, _i32, _i32, _i32, C.c_uint64, _i32, _vp, _vp, _vp,
                             _i64, _vp, _vp, _i32, _vp, _vp, _vp]),
     "msm_gemm_f64": (_i32, [_vp, _i32, _i32, _i32, _vp, _i64, _vp, _i64, _vp, _i64]),
+    "msm_weighted_stats": (_i32, [_vp, _vp, _i64, _i64, _vp, _vp]),
+    "msm_hist2d": (_i32, [_vp, _vp, _i64, _vp, _i64, _i64, _vp, _f64, _vp, _i32, _vp, _i32, _vp]),
+    "msm_smooth_sparse_bins": (_i32, [_vp, _vp, _i32, _i32, _f64, _vp, _vp]),
+    "msm_scale_to_total": (_i32, [_vp, _vp, _i32, _f64]),
+    "msm_fes_finalize": (_i32, [_vp, _vp, _i32, _f64, _vp, _vp]),
+    "msm_kde2d": (_i32, [_vp, _vp, _i64, _vp, _i64, _i64, _vp, _f64, _vp, _i32, _vp, _i32, _f64, _f64, _vp]),
     "msm_ck_test": (_i32, [_vp, _vp, _i64, _vp, _i64, _i64, _i32, _vp, _i32, _vp, _i64, _vp, _vp]),
 }
 

@@ -476,6 +476,57 @@ class Engine:
                                  inv_map.ptr, k, T_full.ptr, pi_full.ptr), self.handle)
         return T_full, pi_full
 
+    # -- free-energy surfaces ---------------------------------------------------
+    def weighted_stats(self, x: DeviceArray, col: int = 0, weights: DeviceArray | None = None) -> np.ndarray:
+        """[sum w, sum w^2, weighted mean, weighted variance, min, max] of column `col` of x [n, d] (or of a
+        1-D array); unit weights when `weights` is None."""
+        if len(x.shape) == 1:
+            n, stride, off = x.shape[0], 1, 0
+        else:
+            n, stride, off = x.shape[0], x.shape[1], int(col)
+        out = self.empty((6,), np.float64)
+        check(lib.msm_weighted_stats(self.handle, x.ptr + off * 8, stride, n, weights.ptr if weights is not None else None,
+                                     out.ptr), self.handle)
+        return out.to_host()
+
+    def hist2d(self, x: DeviceArray, cols, xedges: np.ndarray, yedges: np.ndarray,
+               weights: DeviceArray | None = None, w_absmax: float = 0.0) -> DeviceArray:
+        """np.histogram2d(x[:, cols[0]], x[:, cols[1]], bins=[xedges, yedges], weights=w) -> f64 [nx, ny]."""
+        n, d = x.shape
+        nx, ny = len(xedges) - 1, len(yedges) - 1
+        xe, ye = self.to_device(np.ascontiguousarray(xedges, np.float64)), self.to_device(np.ascontiguousarray(yedges, np.float64))
+        h = self.empty((nx, ny), np.float64)
+        check(lib.msm_hist2d(self.handle, x.ptr + int(cols[0]) * 8, d, x.ptr + int(cols[1]) * 8, d, n,
+                             weights.ptr if weights is not None else None, float(w_absmax), xe.ptr, nx, ye.ptr, ny, h.ptr),
+              self.handle)
+        return h
+
+    def smooth_sparse_bins(self, hist: DeviceArray, min_count: float) -> tuple[DeviceArray, int]:
+        nx, ny = hist.shape
+        out = self.empty((nx, ny), np.float64)
+        cnt = self.empty((1,), np.int32)
+        check(lib.msm_smooth_sparse_bins(self.handle, hist.ptr, nx, ny, float(min_count), out.ptr, cnt.ptr), self.handle)
+        return out, int(cnt.to_host()[0])
+
+    def scale_to_total(self, v: DeviceArray, total: float) -> None:
+        check(lib.msm_scale_to_total(self.handle, v.ptr, v.size, float(total)), self.handle)
+
+    def fes_finalize(self, hist: DeviceArray, kT: float) -> tuple[DeviceArray, int]:
+        F = self.empty(hist.shape, np.float64)
+        st = self.empty((1,), np.int32)
+        check(lib.msm_fes_finalize(self.handle, hist.ptr, hist.size, float(kT), F.ptr, st.ptr), self.handle)
+        return F, int(st.to_host()[0])
+
+    def kde2d(self, x: DeviceArray, cols, xcenters: np.ndarray, ycenters: np.ndarray, bw_x: float, bw_y: float,
+              weights: DeviceArray | None, w_scale: float) -> DeviceArray:
+        n, d = x.shape
+        xc, yc = self.to_device(np.ascontiguousarray(xcenters, np.float64)), self.to_device(np.ascontiguousarray(ycenters, np.float64))
+        dens = self.empty((len(xcenters), len(ycenters)), np.float64)
+        check(lib.msm_kde2d(self.handle, x.ptr + int(cols[0]) * 8, d, x.ptr + int(cols[1]) * 8, d, n,
+                            weights.ptr if weights is not None else None, float(w_scale), xc.ptr, len(xcenters), yc.ptr,
+                            len(ycenters), float(bw_x), float(bw_y), dens.ptr), self.handle)
+        return dens
+
     def gemm(self, A: DeviceArray, B: DeviceArray, out: DeviceArray | None = None) -> DeviceArray:
         """C = A . B (fp64, matrix cores; ascending-k FMA chain per element)."""
         m, k = A.shape

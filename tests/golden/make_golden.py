@@ -290,7 +290,48 @@ def golden_ck():
     np.savez_compressed(OUT / "ck.npz", **out)
 
 
+def golden_fes():
+    """analysis/fes.py: compute_weighted_fes, grid and KDE, weighted and not (whitening off: the
+    dataset carries no DeepTICA metadata)."""
+    from pmarlo.analysis import fes as ref_fes
+
+    rng = np.random.default_rng(404)
+    n = 12000
+    nb = n // 3
+    blobs = np.concatenate([rng.normal([-1.0, 0.5, 0.0], [0.35, 0.6, 0.05], size=(nb, 3)),
+                            rng.normal([1.2, -0.4, 0.0], [0.5, 0.3, 0.05], size=(nb, 3))])
+    flat = rng.uniform([-2.0, -1.5, -0.1], [2.5, 1.8, 0.1], size=(n - 2 * nb, 3))   # keeps every grid bin populated
+    X = np.clip(np.concatenate([blobs, flat]), [-2.0, -1.5, -1.0], [2.5, 1.8, 1.0])
+    X = X[rng.permutation(n)]
+    X = X[:, [2, 0, 1]]                      # the low-variance column first: exercises the component selection
+    w = rng.gamma(2.0, 1.0, size=n)
+    out = {"X": X, "w": w}
+    cases = {
+        "grid_u": dict(method="grid", bins=12, min_count_per_bin=1, weights=None),
+        "grid_w": dict(method="grid", bins=(10, 14), min_count_per_bin=70, weights=w),
+        "grid_s": dict(method="grid", bins=16, min_count_per_bin=25, weights=None),
+        "kde_u": dict(method="kde", bins=16, bandwidth="scott", weights=None),
+        "kde_w": dict(method="kde", bins=(12, 20), bandwidth="silverman", weights=w),
+        "kde_f": dict(method="kde", bins=9, bandwidth=0.3, weights=w, temperature_K=350.0),
+    }
+    for name, kw in cases.items():
+        res = ref_fes.compute_weighted_fes({"splits": {"train": {"X": X.copy()}}}, apply_whitening=False, **kw)
+        out[f"{name}_hist"] = res["histogram"]
+        out[f"{name}_xedges"] = res["xedges"]
+        out[f"{name}_yedges"] = res["yedges"]
+        out[f"{name}_F"] = res["free_energy"]
+        md = res["metadata"]
+        out[f"{name}_sel"] = np.asarray(md["selected_components"])
+        if "bandwidth" in md:
+            b = md["bandwidth"]
+            out[f"{name}_bw"] = np.array([b["x"], b["y"], b["effective_sample_size"], b["total_weight"]])
+        else:
+            out[f"{name}_smoothed"] = np.array([md["smoothed_bins"]])
+    np.savez_compressed(OUT / "fes.npz", **out)
+
+
 if __name__ == "__main__":
+    golden_fes()
     golden_ck()
     golden_counts()
     golden_preprocess_tica()

@@ -1,0 +1,99 @@
+"""Free-energy surfaces on the GPU (msm_weighted_stats, msm_hist2d, msm_smooth_sparse_bins,
+msm_fes_finalize, msm_kde2d) against the golden vectors made by importing the reference's
+analysis/fes.py, and against the oracle on other sizes.
+
+Tolerances: unweighted histograms bit-exact (integer counts); weighted histograms 1e-12 relative
+(2^e fixed point vs numpy's sequential sum); KDE densities 1e-11 relative (sum order, exp);
+free energies 1e-9 absolute kJ/mol."""
+import numpy as np
+import pytest
+
+from oracle import npport
+from pmarlo_amd.analysis.fes import compute_weighted_fes, select_highest_variance_components
+
+pytestmark = pytest.mark.gpu
+
+CASES = [
+    ("grid_u", dict(method="grid", bins=12, min_count_per_bin=1)),
+    ("grid_w", dict(method="grid", bins=(10, 14), min_count_per_bin=70, weighted=True)),
+    ("grid_s", dict(method="grid", bins=16, min_count_per_bin=25)),
+    ("kde_u", dict(method="kde", bins=16, bandwidth="scott")),
+    ("kde_w", dict(method="kde", bins=(12, 20), bandwidth="silverman", weighted=True)),
+    ("kde_f", dict(method="kde", bins=9, bandwidth=0.3, weighted=True, temperature_K=350.0)),
+]
+
+
+@pytest.mark.parametrize("case,kw", CASES)
+def test_compute_weighted_fes_vs_reference_golden(golden, case, kw):
+    g = golden("fes.npz")
+    kw = dict(kw)
+    w = g["w"] if kw.pop("weighted", False) else None
+    out = compute_weighted_fes({"splits": {"train": {"X": g["X"]}}}, weights=w, apply_whitening=False, **kw)
+    md = out["metadata"]
+    assert md["selected_components"] == g[f"{case}_sel"].tolist()
+    assert md["weighted"] == (w is not None) and md["split"] == "train"
+    np.testing.assert_allclose(out["xedges"], g[f"{case}_xedges"], rtol=1e-13, atol=1e-13)
+    np.testing.assert_allclose(out["yedges"], g[f"{case}_yedges"], rtol=1e-13, atol=1e-13)
+    if case == "grid_u":
+        np.testing.assert_array_equal(out["histogram"], g[f"{case}_hist"])     # integer counts
+    else:
+        np.testing.assert_allclose(out["histogram"], g[f"{case}_hist"], rtol=1e-11)
+    np.testing.assert_allclose(out["free_energy"], g[f"{case}_F"], rtol=0, atol=1e-9)
+    if kw["method"] == "kde":
+        b = md["bandwidth"]
+        np.testing.assert_allclose([b["x"], b["y"], b["effective_sample_size"], b["total_weight"]], g[f"{case}_bw"],
+                                   rtol=1e-12)
+    else:
+        assert md["smoothed_bins"] == int(g[f"{case}_smoothed"][0])
+
+
+@pytest.mark.parametrize("n,bins,method", [(300_000, 64, "kde"), (1_000_000, (48, 100), "grid"), (50_001, 70, "kde")])
+def test_fes_vs_oracle_large(n, bins, method):
+    rng = np.random.default_rng(n)
+    X = np.concatenate([np.clip(rng.normal([0, 0, 0, 0], [1.0, 0.01, 2.0, 0.5], size=(n - n // 5, 4)), -5.9, 5.9),
+                        rng.uniform(-6, 6, size=(n // 5, 4)) * [1.0, 0.001, 1.0, 0.1]])   # uniform floor: no empty bins
+    w = rng.gamma(1.5, 1.0, size=n)
+    nk = 20_000 if method == "kde" else n     # the oracle's KDE materialises (bins x N) arrays
+    ds = {"splits": {"a": {"X": X[:nk]}}, "frame_weights": {"a": w[:nk]}}
+    got = compute_weighted_fes(ds, bins=bins, method=method, min_count_per_bin=2, apply_whitening=False)
+    want = npport.weighted_fes(X[:nk], weights=w[:nk], bins=bins, method=method, min_count_per_bin=2)
+    assert got["metadata"]["selected_components"] == want["metadata"]["selected_components"] == [2, 0]
+    np.testing.assert_allclose(got["histogram"], want["histogram"], rtol=1e-10, atol=1e-300)
+    np.testing.assert_allclose(got["free_energy"], want["free_energy"], rtol=0, atol=1e-8)
+    if method == "kde" and n > nk:   # full-size run: finite, normalised density (integrates to ~1 on the padded grid)
+        full = compute_weighted_fes({"splits": {"a": {"X": X}}}, weights=w, bins=bins, method="kde", apply_whitening=False)
+        dx = np.diff(full["xedges"])[0] * np.diff(full["yedges"])[0]
+        assert abs(full["histogram"].sum() * dx - 1.0) < 2e-2 and np.all(np.isfinite(full["free_energy"]))
+
+
+def test_histogram_edge_semantics(engine):
+    """last edge inclusive, values outside dropped, NaN dropped, searchsorted('right') on the edges"""
+    xe = np.linspace(0.0, 1.0, 11)
+    ye = np.array([0.0, 0.5, 1.0])
+    pts = np.array([[0.0, 0.0], [1.0, 1.0], [0.3, 0.5], [0.30000000000000004, 0.25], [0.1 * 3, 0.75], [1.0000001, 0.5],
+                    [-1e-9, 0.5], [np.nan, 0.5], [0.5, np.nan], [0.7, 0.4999999999999999]])
+    h = engine.hist2d(engine.to_device(pts), (0, 1), xe, ye).to_host()
+    ok = np.isfinite(pts).all(axis=1)
+    want, _, _ = np.histogram2d(pts[ok, 0], pts[ok, 1], bins=[xe, ye])
+    np.testing.assert_array_equal(h, want)
+    assert h.sum() == 6
+
+
+def test_errors_and_component_selection():
+    rng = np.random.default_rng(0)
+    X = rng.normal(size=(500, 3)) * [0.1, 5.0, 1.0]
+    coords, sel = select_highest_variance_components(X)
+    assert sel == [1, 2] and coords.shape == (500, 2)
+    with pytest.raises(ValueError):
+        select_highest_variance_components(np.ones((10, 3)))
+    ds = {"splits": {"s": {"X": X}}}
+    with pytest.raises(ValueError):
+        compute_weighted_fes(ds, method="spline", apply_whitening=False)
+    with pytest.raises(ValueError):
+        compute_weighted_fes(ds, weights=-np.ones(500), apply_whitening=False)
+    with pytest.raises(ValueError):
+        compute_weighted_fes(ds, weights=np.ones(3), apply_whitening=False)
+    with pytest.raises(ValueError):    # empty bins stay empty without smoothing -> the reference raises too
+        compute_weighted_fes(ds, method="grid", bins=40, min_count_per_bin=0, apply_whitening=False)
+    with pytest.raises(KeyError):
+        compute_weighted_fes(ds, split="missing", apply_whitening=False)
