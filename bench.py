@@ -34,8 +34,8 @@ HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s
 FP64_MFMA_PEAK_TF = 78.6       # MI355X fp64 matrix (= vector) peak
 # HBM-side bytes per launch of the dominant kernel at the default workload, from the PMC passes in
 # profiles/r01_pmc_hbm.md (2 x FETCH_SIZE + WRITE_SIZE, the gfx950 correction of the guide):
-# reads of Y (80 MB) + next-group prefetch + the atomics flush of the member sums
-KMEANS_ACCUM_TRAFFIC_BYTES = (2 * 44335 + 10571) * 1024
+# reads of Y (80 MB) + the atomics flush of the member sums
+KMEANS_ACCUM_TRAFFIC_BYTES = (2 * 39293 + 10667) * 1024
 
 
 def cpu_baseline(X: np.ndarray) -> dict:
@@ -183,7 +183,7 @@ def main() -> None:
                                    "row-normalised T", "frames_per_gpu": n, "features": N_FEATURES,
                        "tica_dim": TICA_DIM, "k": K_STATES, "lag": LAG, "kmeans_iters": KMEANS_ITERS,
                        "parallelism": f"shards{world}"},
-            "roofline": {"kernel": "kmeans_mfma_kernel<double,3,4,true> (assign + accumulate)", "bound": "mfma",
+            "roofline": {"kernel": "kmeans_mfma_kernel<double,3,2,1024,true,true> (assign + accumulate)", "bound": "mfma",
                          "achieved": achieved_tf, "peak": FP64_MFMA_PEAK_TF, "unit": "TFLOP/s",
                          "frac": achieved_tf / FP64_MFMA_PEAK_TF,
                          "traffic": KMEANS_ACCUM_TRAFFIC_BYTES if n == N_FRAMES else None,

@@ -252,7 +252,7 @@ __device__ void spec_ritz(SpecShared* sh, int p, double* out_re, double* out_im)
 // by a light single-workgroup step per matrix (sum of the row-split partials, and every few
 // steps Gram + Cholesky-QR; Rayleigh-Ritz / residuals / pi / implied timescales at the end).
 // T is stochastic (|lambda| <= 1) so the basis needs no rescaling between orthogonalisations.
-constexpr int kSpecSplits = 8;        // row splits of T per apply launch (fixed-order partial sums)
+constexpr int kSpecSplits = 16;       // row splits of T per apply launch (fixed-order partial sums)
 constexpr int kApplyThreads = 256;    // 4 waves = 4 tiles of 64 columns
 
 // partial[s][j][c] = sum_{i in split s} T[i][j] Z[i][c]

@@ -64,8 +64,13 @@ def main():
     spec = eng.spectrum(tm["T"], n=tm["n_active"], n_its=5, lags=[float(lag)])
     eng.sync(); dt = _t.perf_counter() - t0
     print(f"spectrum (ITS, k={k}): {dt * 1e3:.2f} ms wall, launches {spec['launches']}, residual {spec['residual']}")
+    xe = np.linspace(Yh[:, 0].min(), Yh[:, 0].max(), 65)
+    ye = np.linspace(Yh[:, 1].min(), Yh[:, 1].max(), 65)
+    res["fes_hist2d_64x64"] = timeit(eng, lambda: eng.hist2d(Y, (0, 1), xe, ye))
+    xc, yc = 0.5 * (xe[:-1] + xe[1:]), 0.5 * (ye[:-1] + ye[1:])
+    res["fes_kde2d_64x64"] = timeit(eng, lambda: eng.kde2d(Y, (0, 1), xc, yc, 0.1, 0.1, None, 1.0 / n))
     print(f"config n={n} F={F} d={d} k={k} lag={lag}; eigs", eig.to_host()[:4])
-    flops = {"lagged_moments": 3 * F * F * n, "kmeans_assign": 2 * k * d * n}
+    flops = {"lagged_moments": 3 * F * F * n, "kmeans_assign": 2 * k * d * n, "fes_kde2d_64x64": 2 * 64 * 64 * n}
     bytes_ = {"moments": n * F * 4, "project": n * (F * 4 + d * 8), "count_transitions": n * 4,
               "kmeans_assign": n * (d * 8 + 4), "lagged_moments": n * F * 4}
     for name, (med, mn) in res.items():
