@@ -450,17 +450,63 @@ __device__ bool cholesky_lower(double* M, int n, int ld, JacobiShared* sh) {
     return true;
 }
 
-// X = G^-1 for lower-triangular G (one thread per column, forward substitution); X lower.
-__device__ void lower_inverse(const double* G, double* X, int n, int ld) {
-    for (int c = threadIdx.x; c < n; c += blockDim.x) {
-        for (int i = 0; i < c; ++i) X[i * ld + c] = 0.0;
-        for (int i = c; i < n; ++i) {
-            double sacc = (i == c) ? 1.0 : 0.0;
-            for (int k = c; k < i; ++k) sacc = fma(-G[i * ld + k], X[k * ld + c], sacc);
-            X[i * ld + c] = sacc / G[i * ld + i];
+// Two factorisations in lockstep (same barriers): P = chol(Mp) is only a positive-definiteness
+// probe, Q = chol(Mq) is the factor that is used.  Returns false as soon as Mp loses a pivot
+// (Mq is then unfinished and must not be used).
+__device__ bool cholesky_lower_pair(double* Mp, double* Mq, int n, int ld, JacobiShared* sh) {
+    const int tid = threadIdx.x, nt = blockDim.x;
+    for (int j = 0; j < n; ++j) {
+        if (tid < 2) {
+            double* M = tid == 0 ? Mp : Mq;
+            const double dj = M[j * ld + j];
+            sh->ibc[1 + tid] = dj > 0.0 ? 1 : 0;
+            if (dj > 0.0) M[j * ld + j] = sqrt(dj);
         }
+        __syncthreads();
+        if (!sh->ibc[1] || !sh->ibc[2]) return false;
+        const double pjj = Mp[j * ld + j], qjj = Mq[j * ld + j];
+        for (int i = j + 1 + tid; i < n; i += nt) {
+            Mp[i * ld + j] /= pjj;
+            Mq[i * ld + j] /= qjj;
+        }
+        __syncthreads();
+        const int m = n - j - 1;
+        for (int e = tid; e < m * m; e += nt) {
+            const int a = e / m, b = e - a * m;  // trailing (j+1+a, j+1+b), lower part only
+            if (b <= a) {
+                const int ra = (j + 1 + a) * ld, rb = (j + 1 + b) * ld;
+                Mp[ra + j + 1 + b] -= Mp[ra + j] * Mp[rb + j];
+                Mq[ra + j + 1 + b] -= Mq[ra + j] * Mq[rb + j];
+            }
+        }
+        __syncthreads();
+    }
+    return true;
+}
+
+// X = G^-1 for lower-triangular G; X lower.  Right-looking elimination on [G | I]: per pivot k
+// one scaling of row k and one rank-1 update of the rows below, both fully parallel -- n short
+// steps instead of per-column chains of ~n^2/2 dependent FMAs (a dependent fp64 FMA costs ~44
+// cycles here, a workgroup barrier ~100).  X must not alias G.
+__device__ void lower_inverse(const double* G, double* X, int n, int ld) {
+    const int tid = threadIdx.x, nt = blockDim.x;
+    for (int e = tid; e < n * n; e += nt) {
+        const int i = e / n, c = e - i * n;
+        X[i * ld + c] = i == c ? 1.0 : 0.0;
     }
     __syncthreads();
+    for (int k = 0; k < n; ++k) {
+        const double gkk = G[k * ld + k];
+        for (int c = tid; c <= k; c += nt) X[k * ld + c] /= gkk;
+        __syncthreads();
+        const int rows = n - k - 1, cols = k + 1;
+        for (int e = tid; e < rows * cols; e += nt) {
+            const int a = e / cols, c = e - a * cols;
+            const int i = k + 1 + a;
+            X[i * ld + c] = fma(-G[i * ld + k], X[k * ld + c], X[i * ld + c]);
+        }
+        __syncthreads();
+    }
 }
 
 struct TicaWork {  // global scratch: four n*ld matrices, then ev[n], mean[n], isc[n], order[n]
@@ -471,14 +517,27 @@ struct TicaWork {  // global scratch: four n*ld matrices, then ev[n], mean[n], i
 // C[i][j] = sum_k opA(i,k) * B[k][j]   (opA = A or A'), i < rows, j < cols, k < inner
 __device__ void small_mm(double* C, const double* A, bool transA, const double* B, int rows, int cols, int inner,
                          int ld) {
-    for (int e = threadIdx.x; e < rows * cols; e += blockDim.x) {
-        const int i = e / cols, j = e - i * cols;
-        double a = 0.0;
-        if (transA)
-            for (int k = 0; k < inner; ++k) a = fma(A[k * ld + i], B[k * ld + j], a);
-        else
-            for (int k = 0; k < inner; ++k) a = fma(A[i * ld + k], B[k * ld + j], a);
-        C[i * ld + j] = a;
+    // four output elements per trip: four independent FMA chains hide the fp64 latency
+    const int total = rows * cols, nt = blockDim.x;
+    for (int e0 = threadIdx.x; e0 < total; e0 += 4 * nt) {
+        int ia[4], ja[4];
+        double acc[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int e = min(e0 + u * nt, total - 1);
+            ia[u] = e / cols;
+            ja[u] = e - ia[u] * cols;
+        }
+        for (int k = 0; k < inner; ++k) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const double av = transA ? A[k * ld + ia[u]] : A[ia[u] * ld + k];
+                acc[u] = fma(av, B[k * ld + ja[u]], acc[u]);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (e0 + u * nt < total) C[ia[u] * ld + ja[u]] = acc[u];
     }
     __syncthreads();
 }
@@ -538,17 +597,12 @@ __global__ __launch_bounds__(kEigThreads) void tica_solve_kernel(
     for (int e = tid; e < n * n; e += nt) {
         const int i = e / n, j = e - i * n;
         B2[i * ld + j] = A[i * ld + j] - (i == j ? epsilon : 0.0);
+        V[i * ld + j] = A[i * ld + j];
     }
     __syncthreads();
-    const bool full_rank = cholesky_lower(B2, n, ld, &sh);
+    const bool full_rank = cholesky_lower_pair(B2, V, n, ld, &sh);   // probe on C00 - eps I, factor C00 = G G'
     int rank;
     if (full_rank) {
-        for (int e = tid; e < n * n; e += nt) {
-            const int i = e / n, j = e - i * n;
-            V[i * ld + j] = A[i * ld + j];
-        }
-        __syncthreads();
-        cholesky_lower(V, n, ld, &sh);      // C00 = G G'
         lower_inverse(V, A, n, ld);         // A = G^-1 (lower)
         for (int e = tid; e < n * n; e += nt) {
             const int i = e / n, j = e - i * n;
