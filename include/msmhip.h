@@ -414,6 +414,33 @@ msm_status msm_kde2d(msm_ctx* ctx, const double* d_x, int64_t sx, const double* 
                      int64_t n, const double* d_w, double w_scale, const double* d_xcenters, int nx,
                      const double* d_ycenters, int ny, double bw_x, double bw_y, double* d_density);
 
+/* ---- dense solves on T: committors, reactive flux, lumping, MFPT ---------------------------
+ * msm_solve_f64: A X = B by Gaussian elimination with partial pivoting (first maximal pivot),
+ *   one workgroup; d_A [n, lda] is overwritten by the factors, d_B [n, ldb] by X.
+ *   *d_info = 0, or j + 1 when column j has no non-zero pivot (singular).
+ * msm_reactive_flux replaces the numerics TPTMixin gets from deeptime (S/markov_state_model/
+ *   _tpt.py:39-160, 255-347): d_role[i] = 0 intermediate, 1 source A, 2 sink B;
+ *   q+ : (T - I) q = 0 on intermediates, q = 0 on A, 1 on B;   q- : the same for the time-reversed
+ *   chain pi_j T_ji / pi_i with 1 on A, 0 on B;   gross f_ij = pi_i q-_i T_ij q+_j (i != j);
+ *   net = max(0, f_ij - f_ji);   d_totals = {F = sum_{i in A, j not in A} f_ij, Z = sum_i pi_i q-_i,
+ *   rate F / Z, mfpt Z / F}.  d_info int32 [2] (forward, backward solve).  d_gross / d_net /
+ *   d_totals may be NULL together (committors only).
+ * msm_lump_macro: lump_micro_to_macro_T + compute_macro_populations (S/markov_state_model/
+ *   _msm_utils.py:103-135): F_AB = sum_{i in A, j in B} pi_i T_ij, T_macro = F / rowsum (zero rows
+ *   stay zero), pi_macro[A] = sum_{i in A} pi_i renormalised.
+ * msm_macro_mfpt: compute_macro_mfpt (:138-160): for every target j solve (I - Q_j) t = 1 with
+ *   row / column j removed; d_mfpt f64 [n, n] (column j = times into j, diagonal 0); d_info [n]. */
+msm_status msm_solve_f64(msm_ctx* ctx, int n, int nrhs, double* d_A, int64_t lda, double* d_B,
+                         int64_t ldb, int32_t* d_info);
+msm_status msm_reactive_flux(msm_ctx* ctx, const double* d_T, int64_t ldt, const double* d_pi,
+                             const int32_t* d_role, int n, double* d_qplus, double* d_qminus,
+                             double* d_gross, double* d_net, double* d_totals, int32_t* d_info);
+msm_status msm_lump_macro(msm_ctx* ctx, const double* d_T, int64_t ldt, const double* d_pi,
+                          const int32_t* d_macro, int n, int n_macro, double* d_T_macro,
+                          double* d_pi_macro);
+msm_status msm_macro_mfpt(msm_ctx* ctx, const double* d_T, int64_t ldt, int n, double* d_mfpt,
+                          int32_t* d_info);
+
 #ifdef __cplusplus
 }
 #endif

@@ -632,3 +632,74 @@ def weighted_fes(X, *, weights=None, bins=64, temperature_K=300.0, method="kde",
         raise ValueError("FES method must be either 'kde' or 'grid'")
     return {"histogram": hist, "xedges": xe, "yedges": ye, "free_energy": fes_free_energy(hist, temperature_K),
             "metadata": meta}
+
+
+# ---------------------------------------------------------------------------
+# TPT and lumping (S/markov_state_model/_tpt.py:39-160, 255-347 via deeptime 0.4.5 -- published
+# dense algorithm, parity unpinned; _msm_utils.py:103-160 lumping / populations / MFPT).
+# ---------------------------------------------------------------------------
+def committor(T, source, sink, forward=True, pi=None):
+    T = np.asarray(T, float)
+    n = T.shape[0]
+    A, B = np.unique(np.asarray(source, int)), np.unique(np.asarray(sink, int))
+    if forward:
+        W = T - np.eye(n)
+        r = np.zeros(n)
+        r[B] = 1.0
+    else:
+        pi = stationary_distribution(T) if pi is None else np.asarray(pi, float)
+        W = (pi[None, :] * T.T) / pi[:, None] - np.eye(n)
+        r = np.zeros(n)
+        r[A] = 1.0
+    for S in (A, B):
+        W[S, :] = 0.0
+        W[S, S] = 1.0
+    return np.linalg.solve(W, r)
+
+
+def reactive_flux(T, pi, source, sink):
+    T = np.asarray(T, float)
+    pi = np.asarray(pi, float)
+    qp = committor(T, source, sink, True)
+    qm = committor(T, source, sink, False, pi)
+    gross = (pi * qm)[:, None] * T * qp[None, :]
+    np.fill_diagonal(gross, 0.0)
+    net = np.maximum(0.0, gross - gross.T)
+    A = np.unique(np.asarray(source, int))
+    notA = np.setdiff1d(np.arange(T.shape[0]), A)
+    F = float(gross[np.ix_(A, notA)].sum())
+    Z = float(np.dot(pi, qm))
+    return {"qplus": qp, "qminus": qm, "gross": gross, "net": net, "total_flux": F, "rate": F / Z, "mfpt": Z / F}
+
+
+def macro_populations(pi_micro, micro_to_macro):
+    m = np.asarray(micro_to_macro, int)
+    out = np.bincount(m, weights=np.asarray(pi_micro, float), minlength=int(m.max()) + 1)
+    s = out.sum()
+    return out / s if s > 0 else out
+
+
+def lump_micro_to_macro_T(T_micro, pi_micro, micro_to_macro):
+    m = np.asarray(micro_to_macro, int)
+    nM = int(m.max()) + 1
+    M = np.zeros((T_micro.shape[0], nM))
+    M[np.arange(m.size), m] = 1.0
+    F = M.T @ (np.asarray(pi_micro, float)[:, None] * np.asarray(T_micro, float)) @ M
+    rows = F.sum(axis=1)
+    rows[rows == 0] = 1.0
+    return F / rows[:, None]
+
+
+def macro_mfpt(T_macro):
+    T = np.asarray(T_macro, float)
+    n = T.shape[0]
+    out = np.zeros((n, n))
+    for j in range(n):
+        mask = np.ones(n, bool)
+        mask[j] = False
+        try:
+            t = np.linalg.solve(np.eye(n - 1) - T[np.ix_(mask, mask)], np.ones(n - 1))
+        except np.linalg.LinAlgError:
+            t = np.full(n - 1, np.nan)
+        out[mask, j] = t
+    return out

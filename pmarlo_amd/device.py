@@ -476,6 +476,42 @@ class Engine:
                                  inv_map.ptr, k, T_full.ptr, pi_full.ptr), self.handle)
         return T_full, pi_full
 
+    # -- dense solves on T: committors / flux / lumping / MFPT --------------------------------
+    def solve(self, A: DeviceArray, B: DeviceArray) -> int:
+        """A X = B in place (A -> LU factors, B -> X); returns 0 or the 1-based singular column."""
+        n = A.shape[0]
+        nrhs = 1 if len(B.shape) == 1 else B.shape[1]
+        info = self.empty((1,), np.int32)
+        check(lib.msm_solve_f64(self.handle, n, nrhs, A.ptr, A.shape[1], B.ptr, nrhs, info.ptr), self.handle)
+        return int(info.to_host()[0])
+
+    def reactive_flux(self, T: DeviceArray, pi: DeviceArray, role: np.ndarray, want_flux: bool = True) -> dict:
+        n = T.shape[0]
+        rd = self.to_device(np.ascontiguousarray(role, np.int32))
+        qp, qm = self.empty((n,), np.float64), self.empty((n,), np.float64)
+        info = self.empty((2,), np.int32)
+        gross = net = tot = None
+        if want_flux:
+            gross, net, tot = self.empty((n, n), np.float64), self.empty((n, n), np.float64), self.empty((4,), np.float64)
+        check(lib.msm_reactive_flux(self.handle, T.ptr, n, pi.ptr, rd.ptr, n, qp.ptr, qm.ptr,
+                                    gross.ptr if gross is not None else None, net.ptr if net is not None else None,
+                                    tot.ptr if tot is not None else None, info.ptr), self.handle)
+        return {"qplus": qp, "qminus": qm, "gross": gross, "net": net, "totals": tot, "info": info.to_host()}
+
+    def lump_macro(self, T: DeviceArray, pi: DeviceArray, macro: np.ndarray, n_macro: int):
+        n = T.shape[0]
+        md = self.to_device(np.ascontiguousarray(macro, np.int32))
+        Tm, pm = self.empty((n_macro, n_macro), np.float64), self.empty((n_macro,), np.float64)
+        check(lib.msm_lump_macro(self.handle, T.ptr, n, pi.ptr, md.ptr, n, int(n_macro), Tm.ptr, pm.ptr), self.handle)
+        return Tm, pm
+
+    def macro_mfpt(self, T: DeviceArray):
+        n = T.shape[0]
+        out = self.empty((n, n), np.float64)
+        info = self.empty((n,), np.int32)
+        check(lib.msm_macro_mfpt(self.handle, T.ptr, n, n, out.ptr, info.ptr), self.handle)
+        return out, info.to_host()
+
     # -- free-energy surfaces ---------------------------------------------------
     def weighted_stats(self, x: DeviceArray, col: int = 0, weights: DeviceArray | None = None) -> np.ndarray:
         """[sum w, sum w^2, weighted mean, weighted variance, min, max] of column `col` of x [n, d] (or of a
