@@ -441,6 +441,14 @@ msm_status msm_lump_macro(msm_ctx* ctx, const double* d_T, int64_t ldt, const do
 msm_status msm_macro_mfpt(msm_ctx* ctx, const double* d_T, int64_t ldt, int n, double* d_mfpt,
                           int32_t* d_info);
 
+/* ---- silhouette score (n_states = "auto") ---------------------------------------------------
+ * Replaces sklearn.metrics.silhouette_score in _auto_select_n_states (S/markov_state_model/
+ * clustering.py:156-233).  d_x f64 [n, ld]: the points SORTED BY CLUSTER, cluster c = rows
+ * [h_offsets[c], h_offsets[c+1]); 2 <= k <= 32.  d_samples f64 [n]: s_i = (b_i - a_i) / max(a_i,
+ * b_i) (0 for singleton clusters); *d_score = mean s_i. */
+msm_status msm_silhouette(msm_ctx* ctx, const double* d_x, int64_t n, int d, int64_t ld,
+                          const int64_t* h_offsets, int k, double* d_samples, double* d_score);
+
 #ifdef __cplusplus
 }
 #endif

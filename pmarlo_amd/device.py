@@ -476,6 +476,16 @@ class Engine:
                                  inv_map.ptr, k, T_full.ptr, pi_full.ptr), self.handle)
         return T_full, pi_full
 
+    def silhouette(self, x_sorted: DeviceArray, offsets) -> tuple[float, DeviceArray]:
+        """Mean silhouette coefficient of points sorted by cluster (cluster c = rows offsets[c]:offsets[c+1])."""
+        n, d = x_sorted.shape
+        off = np.ascontiguousarray(offsets, np.int64)
+        samples = self.empty((n,), np.float64)
+        score = self.empty((1,), np.float64)
+        check(lib.msm_silhouette(self.handle, x_sorted.ptr, n, d, d, off.ctypes.data, len(off) - 1, samples.ptr, score.ptr),
+              self.handle)
+        return float(score.to_host()[0]), samples
+
     # -- dense solves on T: committors / flux / lumping / MFPT --------------------------------
     def solve(self, A: DeviceArray, B: DeviceArray) -> int:
         """A X = B in place (A -> LU factors, B -> X); returns 0 or the 1-based singular column."""

@@ -15,7 +15,7 @@ from ..pipeline import MSMPipeline
 
 logger = logging.getLogger("pmarlo")
 
-__all__ = ["ClusteringResult", "cluster_microstates"]
+__all__ = ["ClusteringResult", "cluster_microstates", "silhouette_score"]
 
 _ALLOWED_KW = {"max_iter", "tolerance", "n_init", "init_centers"}
 
@@ -39,6 +39,69 @@ def _fit_once(pipe, yd, k, seed, max_iter, tol, init):
     labels, centers, _ = pipe.cluster(yd, k, seed=seed, max_iter=max_iter, tol=tol, centers=centers0, mindist=md)
     inertia = float(eng.sum_f64(md).to_host()[0])
     return labels, centers, inertia
+
+
+def silhouette_score(X: np.ndarray, labels: np.ndarray) -> float:
+    """sklearn.metrics.silhouette_score (Euclidean) on the GPU: O(n^2 d) pair distances."""
+    X = np.ascontiguousarray(X, dtype=np.float64)
+    labels = np.asarray(labels)
+    uniq, dense = np.unique(labels, return_inverse=True)
+    if not 2 <= uniq.size <= X.shape[0] - 1:
+        raise ValueError(f"Number of labels is {uniq.size}. Valid values are 2 to n_samples - 1 (inclusive)")
+    if uniq.size > 32:
+        raise NotImplementedError("silhouette_score on the device supports at most 32 clusters")
+    order = np.argsort(dense, kind="stable")
+    offsets = np.concatenate([[0], np.cumsum(np.bincount(dense, minlength=uniq.size))])
+    eng = get_engine()
+    score, _ = eng.silhouette(eng.to_device(X[order]), offsets)
+    return score
+
+
+_MAX_SILHOUETTE_POINTS = 200_000
+
+
+def _auto_select_n_states(Y, random_state, *, sample_size, override_n_states, kwargs) -> tuple[int, str]:
+    """k = 4..20 scored by the silhouette coefficient of a k-means fit on (a random subset of) the data
+    (clustering.py:156-233); the best score wins, the first k on ties."""
+    if override_n_states is not None:
+        if override_n_states <= 0:
+            raise ValueError(f"override_n_states must be a positive integer; received {override_n_states}.")
+        return int(override_n_states), f"auto-override={override_n_states}"
+    note = ""
+    Ys = Y
+    if sample_size is not None:
+        if sample_size <= 1:
+            raise ValueError("sample_size must be greater than 1 when sampling for silhouette scoring.")
+        eff = min(int(sample_size), int(Y.shape[0]))
+        idx = np.random.default_rng(random_state).choice(Y.shape[0], size=eff, replace=False)
+        Ys = Y[idx]
+        note = f" sample={eff}"
+    if Ys.shape[0] > _MAX_SILHOUETTE_POINTS:
+        raise ValueError(f"silhouette scoring is O(n^2): pass silhouette_sample_size (got {Ys.shape[0]} points)")
+    eng = get_engine()
+    pipe = MSMPipeline(eng)
+    yd = eng.to_device(np.ascontiguousarray(Ys))
+    Ys64 = np.ascontiguousarray(Ys, dtype=np.float64)
+    seed = 0 if random_state is None else int(random_state)
+    scores = []
+    for k in range(4, 21):
+        if Ys.shape[0] <= k:
+            break
+        # the engine's seeded random-point start has no k-means++ spreading: a few restarts (lowest
+        # inertia wins) keep a poor start from deciding the scan
+        best = None
+        for r in range(max(3, int(kwargs.get("n_init", 1)))):
+            labels, _, inertia = _fit_once(pipe, yd, k, seed + 7919 * r, int(kwargs.get("max_iter", 100)),
+                                           float(kwargs.get("tolerance", 1e-5)), None)
+            if best is None or inertia < best[1]:
+                best = (labels, inertia)
+        lab = best[0].to_host()
+        scores.append((k, silhouette_score(Ys64, lab) if np.unique(lab).size > 1 else -1.0))
+    if not scores:
+        raise ValueError("too few samples for the n_states='auto' scan (needs more than 4)")
+    chosen, best = max(scores, key=lambda t: t[1])
+    logger.info("Auto-selected %d states with silhouette score %.3f", chosen, best)
+    return int(chosen), f"silhouette={best:.3f}{note}"
 
 
 def cluster_microstates(
@@ -69,19 +132,16 @@ def cluster_microstates(
     if unknown:
         raise TypeError(f"Unsupported clustering keyword arguments: {sorted(unknown)}")
     rationale = None
+    if Y.dtype not in (np.float32, np.float64):
+        Y = Y.astype(np.float64)
     if n_states == "auto":
-        if auto_n_states_override is None:
-            raise NotImplementedError("n_states='auto' (silhouette scan) is outside the accelerated path; "
-                                      "pass auto_n_states_override")
-        n_states = int(auto_n_states_override)
-        rationale = f"auto-override={n_states}"
+        n_states, rationale = _auto_select_n_states(Y, random_state, sample_size=silhouette_sample_size,
+                                                    override_n_states=auto_n_states_override, kwargs=kwargs)
     k = int(n_states)
     if k < 1:
         raise ValueError("n_states must be >= 1")
     if Y.shape[0] < k:
         raise ValueError(f"Cannot create {k} clusters from {Y.shape[0]} samples")
-    if Y.dtype not in (np.float32, np.float64):
-        Y = Y.astype(np.float64)
     eng = get_engine()
     pipe = MSMPipeline(eng)
     yd = eng.to_device(np.ascontiguousarray(Y))
