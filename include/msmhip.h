@@ -102,6 +102,13 @@ void msm_graph_destroy(msm_graph* g);
  *       mode 2: 2Q columns [cos_0..cos_{Q-1} | sin_0..sin_{Q-1}] (_features.py:131-142) */
 msm_status msm_featurize_distances(msm_ctx* ctx, const float* d_xyz, int64_t n, int A,
                                    const int32_t* d_pairs, int P, float* d_out, int64_t ld, int col_off);
+/* contacts: 1.0 where the pair distance is <= rcut (nm), else 0.0 (NaN -> 0); Rg: radius of gyration
+ * with unit masses, one column (S/features/builtins.py:89-108, 252-275). */
+msm_status msm_featurize_contacts(msm_ctx* ctx, const float* d_xyz, int64_t n, int A,
+                                  const int32_t* d_pairs, int P, float rcut, float* d_out,
+                                  int64_t ld, int col_off);
+msm_status msm_featurize_rg(msm_ctx* ctx, const float* d_xyz, int64_t n, int A, float* d_out,
+                            int64_t ld, int col_off);
 msm_status msm_featurize_angles(msm_ctx* ctx, const float* d_xyz, int64_t n, int A,
                                 const int32_t* d_triplets, int Tn, float* d_out, int64_t ld, int col_off);
 msm_status msm_featurize_dihedrals(msm_ctx* ctx, const float* d_xyz, int64_t n, int A,

@@ -52,6 +52,8 @@ _PROTOTYPES: dict[str, tuple] = {
     "msm_graph_launch": (_i32, [_vp, _vp]),
     "msm_graph_destroy": (None, [_vp]),
     "msm_featurize_distances": (_i32, [_vp, _vp, _i64, _i32, _vp, _i32, _vp, _i64, _i32]),
+    "msm_featurize_contacts": (_i32, [_vp, _vp, _i64, _i32, _vp, _i32, C.c_float, _vp, _i64, _i32]),
+    "msm_featurize_rg": (_i32, [_vp, _vp, _i64, _i32, _vp, _i64, _i32]),
     "msm_featurize_angles": (_i32, [_vp, _vp, _i64, _i32, _vp, _i32, _vp, _i64, _i32]),
     "msm_featurize_dihedrals": (_i32, [_vp, _vp, _i64, _i32, _vp, _i32, _i32, _vp, _i64, _i32]),
     "msm_count_transitions": (_i32, [_vp, _vp, _i64, _vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp]),

@@ -87,6 +87,47 @@ __global__ __launch_bounds__(kThreads) void dihedrals_kernel(const float* __rest
     }
 }
 
+// contact indicator of one atom pair per column: 1.0 when the distance is <= rcut, else 0.0; a NaN
+// distance (missing coordinates) counts as "no contact" (S/features/builtins.py:252-275)
+__global__ __launch_bounds__(kThreads) void contacts_kernel(const float* __restrict__ xyz, int64_t n, int A,
+                                                           const int* __restrict__ pairs, int P, float rcut,
+                                                           float* __restrict__ out, int64_t ld, int col_off) {
+    const int64_t total = n * P;
+    for (int64_t e = (int64_t)blockIdx.x * kThreads + threadIdx.x; e < total; e += (int64_t)gridDim.x * kThreads) {
+        const int64_t t = e / P;
+        const int f = (int)(e - t * P);
+        const float* fr = xyz + t * A * 3;
+        const V3 v = sub(ld3(fr + 3 * pairs[2 * f + 1]), ld3(fr + 3 * pairs[2 * f]));
+        const float dist = sqrtf(fmaxf(dot(v, v), kEps));
+        out[t * ld + col_off + f] = dist <= rcut ? 1.0f : 0.0f;   // NaN compares false
+    }
+}
+
+// radius of gyration with unit masses (mdtraj.compute_rg as called at S/features/builtins.py:98):
+// sqrt(mean_a |r_a - mean_a r_a|^2); one wave per frame, fp64 accumulation of the fp32 coordinates
+__global__ __launch_bounds__(kThreads) void rg_kernel(const float* __restrict__ xyz, int64_t n, int A,
+                                                     float* __restrict__ out, int64_t ld, int col_off) {
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = ((int64_t)blockIdx.x * kThreads + threadIdx.x) >> 6;
+    const int64_t n_waves = ((int64_t)gridDim.x * kThreads) >> 6;
+    for (int64_t t = wave; t < n; t += n_waves) {
+        const float* fr = xyz + t * A * 3;
+        double sx = 0.0, sy = 0.0, sz = 0.0;
+        for (int a = lane; a < A; a += 64) { sx += fr[3 * a]; sy += fr[3 * a + 1]; sz += fr[3 * a + 2]; }
+        for (int off = 32; off > 0; off >>= 1) {
+            sx += __shfl_xor(sx, off, 64); sy += __shfl_xor(sy, off, 64); sz += __shfl_xor(sz, off, 64);
+        }
+        const double mx = sx / A, my = sy / A, mz = sz / A;
+        double q = 0.0;
+        for (int a = lane; a < A; a += 64) {
+            const double dx = fr[3 * a] - mx, dy = fr[3 * a + 1] - my, dz = fr[3 * a + 2] - mz;
+            q += dx * dx + dy * dy + dz * dz;
+        }
+        for (int off = 32; off > 0; off >>= 1) q += __shfl_xor(q, off, 64);
+        if (lane == 0) out[t * ld + col_off] = (float)sqrt(q / A);
+    }
+}
+
 int grid_for(const msm_ctx* ctx, int64_t total) {
     return (int)std::min<int64_t>(std::max<int64_t>(1, (total + kThreads - 1) / kThreads), (int64_t)ctx->n_cu * 16);
 }
@@ -111,6 +152,29 @@ msm_status msm_featurize_distances(msm_ctx* ctx, const float* d_xyz, int64_t n, 
     if (rs != MSM_OK || n == 0 || P == 0) return rs;
     hipLaunchKernelGGL(distances_kernel, dim3(grid_for(ctx, n * P)), dim3(kThreads), 0, ctx->stream, d_xyz, n, A,
                        d_pairs, P, d_out, ld, col_off);
+    MSM_CHECK_LAUNCH(ctx);
+    return MSM_OK;
+}
+
+msm_status msm_featurize_contacts(msm_ctx* ctx, const float* d_xyz, int64_t n, int A, const int32_t* d_pairs, int P,
+                                  float rcut, float* d_out, int64_t ld, int col_off) {
+    if (!ctx) return MSM_ERR_INVALID;
+    MSM_REQUIRE(ctx, rcut > 0.0f, "msm_featurize_contacts: rcut must be positive");
+    msm_status rs = check_common(ctx, "msm_featurize_contacts", d_xyz, n, A, d_pairs, P, d_out, ld, col_off, P);
+    if (rs != MSM_OK || n == 0 || P == 0) return rs;
+    hipLaunchKernelGGL(contacts_kernel, dim3(grid_for(ctx, n * P)), dim3(kThreads), 0, ctx->stream, d_xyz, n, A, d_pairs,
+                       P, rcut, d_out, ld, col_off);
+    MSM_CHECK_LAUNCH(ctx);
+    return MSM_OK;
+}
+
+msm_status msm_featurize_rg(msm_ctx* ctx, const float* d_xyz, int64_t n, int A, float* d_out, int64_t ld, int col_off) {
+    if (!ctx) return MSM_ERR_INVALID;
+    MSM_REQUIRE(ctx, n >= 0 && A >= 1 && col_off >= 0 && ld >= col_off + 1, "msm_featurize_rg: bad shape");
+    if (n == 0) return MSM_OK;
+    MSM_REQUIRE(ctx, d_xyz && d_out, "msm_featurize_rg: NULL pointer");
+    hipLaunchKernelGGL(rg_kernel, dim3(grid_for(ctx, n * 64)), dim3(kThreads), 0, ctx->stream, d_xyz, n, A, d_out, ld,
+                       col_off);
     MSM_CHECK_LAUNCH(ctx);
     return MSM_OK;
 }

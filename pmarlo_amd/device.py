@@ -205,6 +205,26 @@ class Engine:
         lib.msm_graph_destroy(g)
 
     # -- featurizers -----------------------------------------------------------
+    def featurize_rg(self, xyz: DeviceArray) -> DeviceArray:
+        """Radius of gyration (unit masses) per frame: float32 [n]."""
+        n, A, _ = xyz.shape
+        out = self.empty((n,), np.float32)
+        check(lib.msm_featurize_rg(self.handle, xyz.ptr, n, A, out.ptr, 1, 0), self.handle)
+        return out
+
+    def featurize_contacts(self, xyz: DeviceArray, pairs, rcut: float) -> DeviceArray:
+        """1.0 where the pair distance is <= rcut (nm): float32 [n, P]."""
+        n, A, _ = xyz.shape
+        p = np.ascontiguousarray(pairs, np.int32).reshape(-1, 2)
+        if p.size and (p.min() < 0 or p.max() >= A):
+            raise ValueError(f"atom index out of range [0, {A})")
+        pd_ = self.to_device(p)
+        out = self.empty((n, p.shape[0]), np.float32)
+        check(lib.msm_featurize_contacts(self.handle, xyz.ptr, n, A, pd_.ptr, p.shape[0], float(rcut), out.ptr,
+                                         p.shape[0], 0), self.handle)
+        self.sync()
+        return out
+
     def featurize(self, xyz: DeviceArray, *, pairs=None, triplets=None, quads=None, dihedral_mode: int = 0,
                   out: DeviceArray | None = None) -> DeviceArray:
         """xyz float32 [n, A, 3] -> float32 [n, F]: distance columns, then angle columns, then

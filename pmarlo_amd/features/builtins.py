@@ -11,7 +11,8 @@ import numpy as np
 from ..device import get_engine
 from .base import register_feature
 
-__all__ = ["PhiPsiFeature", "DistanceFeature", "AngleFeature", "DihedralFeature"]
+__all__ = ["PhiPsiFeature", "DistanceFeature", "AngleFeature", "DihedralFeature", "RadiusOfGyrationFeature",
+           "DistancePairFeature", "ContactsPairFeature"]
 
 
 def _device_features(traj, **kw) -> np.ndarray:
@@ -81,5 +82,66 @@ class DihedralFeature(_IndexedFeature):
     name, width, kw, periodic = "dihedral", 4, "quads", True
 
 
-for _cls in (PhiPsiFeature, DistanceFeature, AngleFeature, DihedralFeature):
+class RadiusOfGyrationFeature:
+    """``Rg``: radius of gyration with unit masses (S/features/builtins.py:89-105)."""
+
+    name = "Rg"
+
+    def __init__(self) -> None:
+        self._periodic = np.array([False], dtype=bool)
+        self.labels: list[str] | None = None
+
+    def compute(self, traj, **kwargs) -> np.ndarray:
+        eng = get_engine()
+        out = eng.featurize_rg(eng.to_device(np.ascontiguousarray(traj.xyz, np.float32)))
+        self.labels = ["Rg"]
+        return out.to_host().reshape(-1, 1).astype(float)
+
+    def is_periodic(self) -> np.ndarray:
+        return self._periodic
+
+
+class _PairKwFeature:
+    """Features addressed by ``i=, j=`` keywords (S/features/builtins.py:109-135, 252-275)."""
+
+    def __init__(self) -> None:
+        self._periodic = np.array([False], dtype=bool)
+        self.labels: list[str] | None = None
+
+    @staticmethod
+    def _pair(traj, kwargs) -> list[int]:
+        i, j = int(kwargs.get("i", -1)), int(kwargs.get("j", -1))
+        if not (0 <= i < traj.n_atoms) or not (0 <= j < traj.n_atoms):
+            raise ValueError("Atom indices out of range")
+        return [i, j]
+
+    def is_periodic(self) -> np.ndarray:
+        return self._periodic
+
+
+class DistancePairFeature(_PairKwFeature):
+    name = "distance_pair"
+
+    def compute(self, traj, **kwargs) -> np.ndarray:
+        i, j = self._pair(traj, kwargs)
+        d = _device_features(traj, pairs=[[i, j]]).astype(float)
+        self.labels = [f"dist:atoms:{i}-{j}"]
+        return np.nan_to_num(d, nan=0.0, posinf=0.0, neginf=0.0)
+
+
+class ContactsPairFeature(_PairKwFeature):
+    name = "contacts_pair"
+
+    def compute(self, traj, **kwargs) -> np.ndarray:
+        rcut = float(kwargs.get("rcut", 0.5))
+        if rcut <= 0:
+            raise ValueError("rcut must be positive")
+        i, j = self._pair(traj, kwargs)
+        eng = get_engine()
+        out = eng.featurize_contacts(eng.to_device(np.ascontiguousarray(traj.xyz, np.float32)), [[i, j]], rcut)
+        return out.to_host().astype(float)
+
+
+for _cls in (PhiPsiFeature, DistanceFeature, AngleFeature, DihedralFeature, RadiusOfGyrationFeature,
+             DistancePairFeature, ContactsPairFeature):
     register_feature(_cls())

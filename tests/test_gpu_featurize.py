@@ -64,3 +64,30 @@ def test_bad_indices_raise(engine):
     xyz = engine.to_device(np.zeros((2, 4, 3), np.float32))
     with pytest.raises(ValueError):
         engine.featurize(xyz, pairs=[[0, 4]])
+
+
+def test_rg_distance_pair_contacts_pair(engine, golden):
+    """S/features/builtins.py:89-135, 252-275 (mdtraj.compute_rg with unit masses; contact = d <= rcut)."""
+    from pmarlo_amd.api.features import compute_features
+    from pmarlo_amd.features import get_feature
+    from pmarlo_amd.io import Topology, Trajectory
+
+    g = golden("featurizer.npz")
+    xyz = np.tile(g["chig_xyz"], (40, 1, 1)).astype(np.float32)
+    xyz += np.random.default_rng(0).normal(0, 0.03, size=xyz.shape).astype(np.float32)
+    A = xyz.shape[1]
+    traj = Trajectory(xyz, Topology([f"X{i}" for i in range(A)], ["UNK"] * A, np.zeros(A, dtype=int)))
+    X, cols, per = compute_features(traj, ["Rg", "distance_pair(i=3, j=90)", "contacts_pair(i=3, j=90, rcut=0.9)"])
+    x64 = xyz.astype(np.float64)
+    rg = np.sqrt(((x64 - x64.mean(axis=1, keepdims=True)) ** 2).sum(axis=2).mean(axis=1))
+    d = np.linalg.norm(x64[:, 90] - x64[:, 3], axis=1)
+    np.testing.assert_allclose(X[:, 0], rg, rtol=2e-6)
+    np.testing.assert_allclose(X[:, 1], d, rtol=2e-6)
+    far = np.abs(d - 0.9) > 1e-5                       # away from the threshold the indicator is exact
+    np.testing.assert_array_equal(X[far, 2], (d[far] <= 0.9).astype(float))
+    assert 0 < X[:, 2].sum() < X.shape[0]
+    assert cols == ["Rg", "dist:atoms:3-90", "contacts_pair"] and per.tolist() == [False, False, False]
+    with pytest.raises(ValueError):
+        get_feature("contacts_pair").compute(traj, i=0, j=1, rcut=0.0)
+    with pytest.raises(ValueError):
+        get_feature("distance_pair").compute(traj, i=0, j=A)
