@@ -64,6 +64,7 @@ def tica_fit_transform_trajectories(features: np.ndarray, traj_lengths: Sequence
     """_maybe_apply_tica: dims clamped to [2, 5], fit on the list of trajectories (no
     standardisation there), transform each, drop the last ``lag`` frames of each, vstack."""
     n_components = int(max(2, min(5, n_components_hint)))
+    drop = int(max(0, lag or 0))          # lag 0: fitted at lag 1, nothing dropped (_features.py:200, 216-231)
     lag = int(max(1, lag or 1))
     Xm = _as_matrix(features)
     edges = np.concatenate([[0], np.cumsum([int(v) for v in traj_lengths])])
@@ -82,5 +83,5 @@ def tica_fit_transform_trajectories(features: np.ndarray, traj_lengths: Sequence
     Y = pipe.tica_transform(model, xd).to_host()
     keep: List[np.ndarray] = []
     for a, b in segs:
-        keep.append(Y[a:b - lag] if b - a > lag else np.empty((0, Y.shape[1])))
+        keep.append(Y[a:b - drop] if b - a > drop else np.empty((0, Y.shape[1])))
     return (np.vstack(keep) if keep else Y), model

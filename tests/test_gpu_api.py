@@ -296,3 +296,48 @@ def test_feature_registry_and_featurize_trajectory(engine, tmp_path):
     register_feature(Mine())
     assert get_feature("PHI_PSI").compute(traj).shape == (500, 1)
     register_feature(phi_psi)
+
+
+def test_compute_msm_features_layouts_and_tica_step(engine, golden):
+    """FeaturesMixin.compute_features (S/markov_state_model/_features.py:23-97, 131-171, 181-231):
+    block layout [cos phi | sin phi | cos psi | sin psi], every-third-C-alpha distance pairs, stride,
+    TICA clamp to [2, 5] with the last lag frames of every trajectory dropped."""
+    from pmarlo_amd.io import Topology, Trajectory
+    from pmarlo_amd.markov_state_model import ca_distance_pairs, compute_msm_features
+
+    g = golden("featurizer.npz")
+    rng = np.random.default_rng(5)
+    # alanine dipeptide: 22 atoms, phi = [4, 6, 8, 14], psi = [6, 8, 14, 16]
+    names = ["X"] * 22
+    resid = np.zeros(22, dtype=int)
+    for idx, (nm, r) in {4: ("C", 0), 6: ("N", 1), 8: ("CA", 1), 14: ("C", 1), 16: ("N", 2)}.items():
+        names[idx], resid[idx] = nm, r
+    resid[15:] = 2
+    resid[5:15] = 1
+    top = Topology(names, ["ALA"] * 22, resid, ["A"] * 22)
+    assert top.phi_indices().tolist() == [[4, 6, 8, 14]] and top.psi_indices().tolist() == [[6, 8, 14, 16]]
+    trajs = []
+    for n in (400, 250):
+        xyz = np.tile(g["ala_xyz"][:1], (n, 1, 1)).astype(np.float32)
+        trajs.append(Trajectory(xyz + rng.normal(0, 0.03, size=xyz.shape).astype(np.float32), top))
+    out = compute_msm_features(trajs, "phi_psi", feature_stride=2)
+    assert out.raw_frames == 650 and out.strided_frames == 325 and out.traj_lengths == [200, 125]
+    x0 = trajs[0].xyz[::2].astype(np.float64)
+    phi = npport.dihedrals(x0, [[4, 6, 8, 14]])[:, 0]
+    psi = npport.dihedrals(x0, [[6, 8, 14, 16]])[:, 0]
+    want = np.column_stack([np.cos(phi), np.sin(phi), np.cos(psi), np.sin(psi)])
+    np.testing.assert_allclose(out.features[:200], want, atol=3e-5)
+    # TICA step: hint 9 -> 5 dims is impossible with 4 features -> rank-limited to <= 4; lag frames dropped per trajectory
+    red = compute_msm_features(trajs, "phi_psi", tica_lag=3, tica_components=2)
+    assert red.features.shape == (400 - 3 + 250 - 3, 2) and red.traj_lengths == [397, 247]
+    red0 = compute_msm_features(trajs, "phi_psi", tica_lag=0, tica_components=2)
+    assert red0.features.shape == (650, 2)                      # lag 0: fitted at lag 1, nothing dropped
+    # every third C-alpha, j >= i + 3, capped
+    ca = list(range(0, 60, 2))                                    # 30 "C-alpha" atoms
+    pairs = ca_distance_pairs(ca, None)
+    assert pairs[0].tolist() == [0, 6] and pairs[1].tolist() == [0, 12] and len(pairs) == 45
+    assert len(ca_distance_pairs(ca, 7)) == 7
+    with pytest.raises(ValueError):
+        ca_distance_pairs([3], None)
+    with pytest.raises(ValueError):
+        compute_msm_features(trajs, "bogus")
