@@ -639,15 +639,26 @@ class Engine:
         its_ts = self.empty((B, max(n_its, 1)), np.float64)
         lag_d = self.to_device(np.asarray(lags if lags is not None else np.ones(B), np.float64).reshape(B))
         launches = 0
+        restart = True
+        since_restart = 0
+        worst = float("inf")
         for launch in range(max_launches):
             check(lib.msm_spectrum(self.handle, T.ptr, k * k, k, n.ptr if n is not None else None, k, B, p,
-                                   int(n_iter), int(launch == 0), int(seed), max(n_its + 1, 1), ws.ptr, ritz.ptr,
+                                   int(n_iter), int(restart), int(seed), max(n_its + 1, 1), ws.ptr, ritz.ptr,
                                    pi.ptr if pi is not None else None, k, change.ptr, status.ptr, int(n_its),
                                    lag_d.ptr, its_eig.ptr, its_ts.ptr), self.handle)
             launches += 1
+            restart = False
+            since_restart += 1
             worst = float(np.max(change.to_host()))
             if worst <= tol:
                 break
+            # slow convergence = the watched eigenvalues are close to lambda_{p+1}: a wider basis moves
+            # that ratio down at little cost per iteration (restart with twice the subspace, up to 32)
+            if since_restart >= 8 and p < min(32, k):
+                p = int(min(32, k, 2 * p))
+                ws = self.empty((int(lib.msm_spectrum_workspace_bytes(k, p, B)),), np.uint8)
+                restart, since_restart = True, 0
         else:
             if not allow_unconverged:
                 raise _lib.MsmError(
