@@ -12,7 +12,8 @@ exchanged, by plain summation over RCCL/xGMI (``torch.distributed``, backend "nc
   transition counts             k^2 int64 (exact)               once
 
 Integer payloads make the result independent of the number of shards bit for bit; the fp64
-moment sums are order-dependent only at the last bit across ranks.  With ``comm=None`` the
+moment sums are gathered and added in rank order (bit-identical on every rank, independent of the
+collective's schedule).  With ``comm=None`` the
 same code runs on a single GPU (bench.py at N=1, tests).
 """
 
@@ -50,9 +51,27 @@ class TorchComm(Comm):
         self.t = tensors
         self.world = dist.get_world_size()
         self.rank = dist.get_rank()
+        self._gather: dict = {}
 
     def allreduce_sum(self, name):
-        self.dist.all_reduce(self.t[name], op=self.dist.ReduceOp.SUM)
+        t = self.t[name]
+        if not t.dtype.is_floating_point:
+            # integer sums commute: any reduction schedule gives the same bits
+            self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
+            return
+        # fp64 moment sums: gather every rank's buffer and add them in rank order, so the result
+        # does not depend on the collective's internal schedule and is bit-identical on all ranks
+        # (these buffers are <= a few hundred KB: latency-bound either way)
+        import torch
+
+        parts = self._gather.get(name)
+        if parts is None:
+            parts = [torch.empty_like(t) for _ in range(self.world)]
+            self._gather[name] = parts
+        self.dist.all_gather(parts, t)
+        t.copy_(parts[0])
+        for r in range(1, self.world):
+            t.add_(parts[r])
 
     def allreduce_min(self, name):
         self.dist.all_reduce(self.t[name], op=self.dist.ReduceOp.MIN)
