@@ -197,7 +197,7 @@ def main() -> None:
             from oracle import cport, npport
 
             counts = msm.buf["counts"].view((K_STATES, K_STATES)).to_host()
-            pairs = int(msm.buf["pairs"].to_host()[0])
+            pairs = int(msm.buf["counts"].view((1,), offset_elems=K_STATES * K_STATES).to_host()[0])
             labels = msm.labels.to_host()
             if not multi:
                 want, pw = cport.count_transitions(labels, K_STATES, LAG)

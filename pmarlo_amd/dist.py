@@ -39,6 +39,7 @@ class Comm:
     def allreduce_min(self, name: str) -> None: ...
     def allreduce_max(self, name: str) -> None: ...
     def broadcast(self, name: str, src: int = 0) -> None: ...
+    def reciprocal(self, dst: str, src: str) -> None: ...
 
 
 class TorchComm(Comm):
@@ -82,6 +83,12 @@ class TorchComm(Comm):
     def broadcast(self, name, src=0):
         self.dist.broadcast(self.t[name], src=src)
 
+    def reciprocal(self, dst, src):
+        """t[dst] = 1 / t[src] on the exchange stream (a torch elementwise op, ordered with the collectives)."""
+        import torch
+
+        torch.reciprocal(self.t[src], out=self.t[dst])
+
 
 @dataclass
 class ShardConfig:
@@ -105,8 +112,7 @@ def exchange_shapes(cfg: ShardConfig) -> dict[str, tuple[tuple[int, ...], str]]:
         "fit_state": ((8,), "float64"),
         "centers": ((k, d), "float64"),
         "km_acc": ((k * d + k,), "int64"),
-        "counts": ((k * k,), "int64"),
-        "pairs": ((1,), "int64"),
+        "counts": ((k * k + 1,), "int64"),   # the pair count rides at the end: one collective
     }
 
 
@@ -174,7 +180,7 @@ class ShardedMSM:
             # (state = {scale, inv_scale, ...}: MIN of scale, inv_scale follows as MAX)
             comm.broadcast("centers", 0)
             comm.allreduce_min("fit_scale")
-            comm.allreduce_max("fit_inv_scale")
+            comm.reciprocal("fit_inv_scale", "fit_scale")   # 2^-e: exact, no second collective
         check(lib.msm_memset(eng.handle, b["km_acc"].ptr, 0, b["km_acc"].nbytes), eng.handle)
         for _ in range(cfg.kmeans_iters):
             if self.time_accum:
@@ -189,10 +195,10 @@ class ShardedMSM:
             eng.kmeans_update(self.km_sums, self.km_counts, b["centers"], b["fit_state"], clear=True)
         eng.kmeans_assign(self.Y, b["centers"], labels=self.labels)
         # 5. lag-tau counts + row-normalised transition matrix
-        eng.count_transitions(self.labels, k, cfg.lag, out=b["counts"].view((k, k)), pairs=b["pairs"])
+        eng.count_transitions(self.labels, k, cfg.lag, out=b["counts"].view((k, k)),
+                              pairs=b["counts"].view((1,), offset_elems=k * k))
         if multi:
             comm.allreduce_sum("counts")
-            comm.allreduce_sum("pairs")
         check(lib.msm_transition_matrix(eng.handle, b["counts"].ptr, 0, k, 0, 0.0, 0.0, self.T.ptr, None, None, None,
                                         self.rowsum.ptr, self.diag.ptr), eng.handle)
 

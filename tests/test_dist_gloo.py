@@ -63,8 +63,9 @@ def _worker(rank: int, world: int, port: int, out_dir: str) -> None:
     tensors["fit_state"][0] = float(np.ldexp(1.0, e))
     tensors["fit_state"][1] = float(np.ldexp(1.0, -e))
     comm.allreduce_min("fit_scale")
-    comm.allreduce_max("fit_inv_scale")
+    comm.reciprocal("fit_inv_scale", "fit_scale")
     scale = float(tensors["fit_state"][0])
+    assert float(tensors["fit_state"][1]) * scale == 1.0   # power of two: the reciprocal is exact
     if rank == 0:
         tensors["centers"].copy_(torch.from_numpy(Y[:: n // k][:k].copy()))
     comm.broadcast("centers", 0)
@@ -76,10 +77,9 @@ def _worker(rank: int, world: int, port: int, out_dir: str) -> None:
     tensors["km_acc"].copy_(torch.from_numpy(acc))
     comm.allreduce_sum("km_acc")
     c, p = cport.count_transitions(lab, k, lag)
-    tensors["counts"].copy_(torch.from_numpy(c.ravel()))
-    tensors["pairs"][0] = p
+    tensors["counts"][:k * k].copy_(torch.from_numpy(c.ravel()))
+    tensors["counts"][k * k] = p        # the pair count rides at the end of the counts buffer
     comm.allreduce_sum("counts")
-    comm.allreduce_sum("pairs")
     if rank == 0:
         np.savez(os.path.join(out_dir, "merged.npz"), **{k_: v.numpy() for k_, v in tensors.items()}, mean=mean,
                  sigma=sigma, scale=scale)
@@ -116,8 +116,8 @@ def test_two_rank_exchange_equals_single_shard(tmp_path):
     acc[k * d:] = np.bincount(lab, minlength=k)
     np.testing.assert_array_equal(g["km_acc"], acc)
     want = sum(cport.count_transitions(lab[r * n:(r + 1) * n], k, lag)[0] for r in range(world))
-    np.testing.assert_array_equal(g["counts"].reshape(k, k), want)
-    assert int(g["pairs"][0]) == world * (n - lag)
+    np.testing.assert_array_equal(g["counts"][:k * k].reshape(k, k), want)
+    assert int(g["counts"][k * k]) == world * (n - lag)
     # scale agreed on by all ranks is the coarsest one
     amax = max(np.abs(((X - g["mean"]) / g["sigma"])[:, :d]).max() for X in Xs)
     assert float(g["scale"]) <= np.ldexp(1.0, 61 - int(np.ceil(np.log2(n * world * amax)))) * (1 + 1e-15)
@@ -132,4 +132,4 @@ def test_exchange_payload_sizes_match_survey():
     assert nbytes["mom_sums"] == 3 * 64 * 8                     # ~1.5 KB
     assert nbytes["lagged"] == (2 * 64 * 64 + 2 * 64 + 1) * 8   # ~66 KB
     assert nbytes["km_acc"] == (500 * 10 + 500) * 8             # 44 KB per Lloyd iteration
-    assert nbytes["counts"] == 500 * 500 * 8                    # 2 MB
+    assert nbytes["counts"] == (500 * 500 + 1) * 8              # 2 MB (+ the pair count)
