@@ -21,6 +21,10 @@ struct msm_ctx {
     // is only (re)allocated outside stream capture.
     void* scratch = nullptr;
     size_t scratch_bytes = 0;
+    // second, small scratch for tables a kernel needs WHILE the main scratch is lent to its caller
+    // (half-norms of the k-means centres during msm_kmeans_fit, whose member sums live in `scratch`)
+    void* aux = nullptr;
+    size_t aux_bytes = 0;
     // pinned host staging for small tables (segment lists with > MSM_SEG_INLINE entries)
     void* pinned = nullptr;
     size_t pinned_bytes = 0;
@@ -39,6 +43,7 @@ struct msm_graph {
 msm_status msm_fail(msm_ctx* ctx, msm_status st, const char* fmt, ...);
 // Ensure ctx->scratch holds at least `bytes`; fails during capture if growth is needed.
 msm_status msm_reserve_scratch(msm_ctx* ctx, size_t bytes);
+msm_status msm_reserve_aux(msm_ctx* ctx, size_t bytes);
 
 #define MSM_HIP(ctx, call)                                                              \
     do {                                                                                \

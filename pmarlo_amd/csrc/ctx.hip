@@ -29,6 +29,20 @@ msm_status msm_reserve_scratch(msm_ctx* ctx, size_t bytes) {
     return MSM_OK;
 }
 
+msm_status msm_reserve_aux(msm_ctx* ctx, size_t bytes) {
+    if (bytes <= ctx->aux_bytes) return MSM_OK;
+    if (ctx->capturing)
+        return msm_fail(ctx, MSM_ERR_UNSUPPORTED, "auxiliary scratch must grow to %zu bytes during graph capture", bytes);
+    MSM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (ctx->aux) MSM_HIP(ctx, hipFree(ctx->aux));
+    ctx->aux = nullptr;
+    ctx->aux_bytes = 0;
+    const size_t want = bytes + bytes / 4 + (64u << 10);
+    MSM_HIP(ctx, hipMalloc(&ctx->aux, want));
+    ctx->aux_bytes = want;
+    return MSM_OK;
+}
+
 static msm_status reserve_tables(msm_ctx* ctx, size_t bytes) {
     if (bytes <= ctx->pinned_bytes) return MSM_OK;
     if (ctx->capturing)
@@ -129,6 +143,7 @@ void msm_ctx_destroy(msm_ctx* ctx) {
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
     if (ctx->scratch) (void)hipFree(ctx->scratch);
+    if (ctx->aux) (void)hipFree(ctx->aux);
     if (ctx->dtab) (void)hipFree(ctx->dtab);
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);

@@ -257,12 +257,27 @@ __device__ unsigned long long g_km_stamps[8];
 #define KSTAMP_FLUSH
 #endif
 
-template <typename T, int KS, int NF, int kMT, bool ACCUM, bool FOLD>
+// |c_j|^2 / 2 as the ascending-feature FMA chain (multi-chunk launches: once per launch instead of
+// once per workgroup and chunk)
+__global__ void chalf_kernel(const double* __restrict__ centers, int k, int d, double* __restrict__ out) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= k) return;
+    double a = 0.0;
+    for (int f = 0; f < d; ++f) {
+        const double c = centers[(size_t)j * d + f];
+        a = fma(c, c, a);
+    }
+    out[j] = 0.5 * a;
+}
+
+// MULTI: the centres do not fit one LDS tile and are staged chunk by chunk (k > tile_k).
+template <typename T, int KS, int NF, int kMT, bool ACCUM, bool FOLD, bool MULTI>
 __global__ __launch_bounds__(kMT, kMT == 1024 ? 4 : 2) void kmeans_mfma_kernel(
     const T* __restrict__ x, int64_t n, int d, int64_t ld, const double* __restrict__ centers, int k,
     const double* __restrict__ mean, const double* __restrict__ stdv, int tile_k /* multiple of 16 */,
     int32_t* __restrict__ labels, double* __restrict__ mindist, const FitState* __restrict__ st,
-    unsigned long long* __restrict__ sums, unsigned long long* __restrict__ counts, int lds_acc) {
+    unsigned long long* __restrict__ sums, unsigned long long* __restrict__ counts, int lds_acc,
+    const double* __restrict__ chalf_g /* [k] when MULTI or KS > 8 */) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     // centre tile, k-step major so that a wave's A read is one contiguous 512-byte run:
     // cs[(j / 16) * TS + s * 64 + g * 16 + (j % 16)] = C[k0 + j][4s + g].  The tile stride TS
@@ -293,28 +308,51 @@ __global__ __launch_bounds__(kMT, kMT == 1024 ? 4 : 2) void kmeans_mfma_kernel(
     // stage centre tile [k0, k0 + kt): coordinates, then |c|^2/2 (ascending-feature FMA chain),
     // then (fold) the spare slot
     auto stage_tile = [&](int k0, int kt, int kt16) {
-        for (int i = tid; i < kt16 * 4 * KS; i += kMT) {
-            const int jt = i / (KS * 64);
-            const int rem = i - jt * (KS * 64);
-            const int s = rem >> 6, gg = (rem >> 4) & 3, jj = rem & 15;
-            const int j = jt * 16 + jj, f = 4 * s + gg;
-            cs[jt * TS + rem] = (j < kt && f < d) ? centers[(size_t)(k0 + j) * d + f] : 0.0;
+        // 8 independent loads in flight per thread (the chunked case restages every frame round: a
+        // one-load-per-trip loop spent most of its time waiting on L2)
+        const int total = kt16 * 4 * KS;
+        for (int i0 = tid; i0 < total; i0 += 8 * kMT) {
+            double v[8];
+            int dst[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const int i = min(i0 + q * kMT, total - 1);
+                const int jt = i / (KS * 64);
+                const int rem = i - jt * (KS * 64);
+                const int s = rem >> 6, gg = (rem >> 4) & 3, jj = rem & 15;
+                const int j = jt * 16 + jj, f = 4 * s + gg;
+                const bool ok = j < kt && f < d;
+                v[q] = centers[(size_t)(k0 + (ok ? j : 0)) * d + (ok ? f : 0)];
+                if (!ok) v[q] = 0.0;
+                dst[q] = jt * TS + rem;
+            }
+#pragma unroll
+            for (int q = 0; q < 8; ++q)
+                if (i0 + q * kMT < total) cs[dst[q]] = v[q];
         }
         __syncthreads();
         for (int j = tid; j < kt16; j += kMT) {
-            double a = 0.0;
             double* cj = cs + (j >> 4) * TS + (j & 15);
-            for (int f = 0; f < d; ++f) {
-                const double c = cj[(f >> 2) * 64 + (f & 3) * 16];
-                a = fma(c, c, a);
+            double h = __builtin_inf();  // padding centres can never win
+            if (j < kt) {
+                if constexpr (MULTI) h = chalf_g[k0 + j];
+                else {
+                    double a = 0.0;
+                    for (int f = 0; f < d; ++f) {
+                        const double c = cj[(f >> 2) * 64 + (f & 3) * 16];
+                        a = fma(c, c, a);
+                    }
+                    h = 0.5 * a;
+                }
             }
-            const double h = j < kt ? 0.5 * a : __builtin_inf();  // padding centres can never win
             chalf[j] = h;
             if (fold) cj[fold_s * 64 + fold_g * 16] = -h;
         }
         __syncthreads();
     };
-    const bool single_tile = k <= tile_k;  // the usual case: the tile is staged once per workgroup
+    constexpr bool single_tile = !MULTI;  // the usual case: the tile is staged once per workgroup
+    // winner recovery from the LDS tile (narrow frames, one chunk) or from the global centre table
+    constexpr bool kGlobalRecovery = MULTI || KS > 8;
     __shared__ int unit_ctr;
     KSTAMP_INIT
     if (tid == 0) unit_ctr = kMT / 64;  // groups 0 .. waves-1 of the block's range are taken statically
@@ -398,42 +436,67 @@ __global__ __launch_bounds__(kMT, kMT == 1024 ? 4 : 2) void kmeans_mfma_kernel(
 #pragma unroll
         for (int u = 0; u < NF; ++u) { bm[u] = -__builtin_inf(); bidx[u] = 0; }
 
+        // running maximum and the tile pair it came from.  MULTI: carried across the chunks, the pair
+        // is remembered as (global index of its first tile) * 2 + (second tile == first tile)
+        double best[NF];
+        int bpair[NF];
+#pragma unroll
+        for (int u = 0; u < NF; ++u) { best[u] = -__builtin_inf(); bpair[u] = 0; }
         for (int k0 = 0; k0 < k; k0 += tile_k) {
             const int kt = min(tile_k, k - k0);
             const int kt16 = (kt + 15) & ~15;
             if (!single_tile) {
-                __syncthreads();  // previous chunk fully consumed (its recovery included)
+                __syncthreads();  // previous chunk fully consumed
                 stage_tile(k0, kt, kt16);
+                KSTAMP(5);
             }
             const int n_tiles = kt16 / 16;
             // ---- tile loop, two 16-centre tiles per trip.  Per lane and frame group only the
             // running maximum over everything seen so far and the PAIR it came from are kept:
             // 22 VALU instructions per pair of wave-tiles (every VALU issue costs matrix-pipe time
             // on this chip, tools/probe/valu_mix_probe.hip), no arithmetic on the scores.
-            double best[NF];
-            int bpair[NF];
-#pragma unroll
-            for (int u = 0; u < NF; ++u) { best[u] = -__builtin_inf(); bpair[u] = 0; }
             for (int jt = 0; jt < n_tiles; jt += 2) {
                 const int jb = min(jt + 1, n_tiles - 1);  // odd tile count: the last tile twice
                 v4f64 acca[NF], accb[NF];
 #pragma unroll
                 for (int u = 0; u < NF; ++u) { acca[u] = (v4f64){0.0, 0.0, 0.0, 0.0}; accb[u] = acca[u]; }
-                // all of tile a, then all of tile b (the max tree below relies on tile a being
-                // complete when tile b's last MFMA has issued); A fragments stream from LDS
+                if constexpr (KS <= 4) {
+                    // all of tile a, then all of tile b (the max tree below relies on tile a being
+                    // complete when tile b's last MFMA has issued); A fragments stream from LDS
 #pragma unroll
-                for (int s = 0; s < KS; ++s) {
-                    const double afa = cs[jt * TS + s * 64 + lane];
+                    for (int s = 0; s < KS; ++s) {
+                        const double afa = cs[jt * TS + s * 64 + lane];
 #pragma unroll
-                    for (int u = 0; u < NF; ++u)
-                        acca[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(afa, zb[u][s], acca[u], 0, 0, 0);
-                }
+                        for (int u = 0; u < NF; ++u)
+                            acca[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(afa, zb[u][s], acca[u], 0, 0, 0);
+                    }
 #pragma unroll
-                for (int s = 0; s < KS; ++s) {
-                    const double afb = cs[jb * TS + s * 64 + lane];
+                    for (int s = 0; s < KS; ++s) {
+                        const double afb = cs[jb * TS + s * 64 + lane];
 #pragma unroll
-                    for (int u = 0; u < NF; ++u)
-                        accb[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(afb, zb[u][s], accb[u], 0, 0, 0);
+                        for (int u = 0; u < NF; ++u)
+                            accb[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(afb, zb[u][s], accb[u], 0, 0, 0);
+                    }
+                } else {
+                    // wide frames keep one or two frame groups per wave: the two tiles are interleaved
+                    // (2 NF independent accumulator chains instead of NF) and the A fragments of the
+                    // next k-step are requested before the MFMAs of this one
+                    double fa = cs[jt * TS + lane], fb = cs[jb * TS + lane];
+#pragma unroll
+                    for (int s = 0; s < KS; ++s) {
+                        double na = fa, nb = fb;
+                        if (s + 1 < KS) {
+                            na = cs[jt * TS + (s + 1) * 64 + lane];
+                            nb = cs[jb * TS + (s + 1) * 64 + lane];
+                        }
+#pragma unroll
+                        for (int u = 0; u < NF; ++u) {
+                            acca[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa, zb[u][s], acca[u], 0, 0, 0);
+                            accb[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(fb, zb[u][s], accb[u], 0, 0, 0);
+                        }
+                        fa = na;
+                        fb = nb;
+                    }
                 }
                 if constexpr (!fold) {
 #pragma unroll
@@ -446,6 +509,7 @@ __global__ __launch_bounds__(kMT, kMT == 1024 ? 4 : 2) void kmeans_mfma_kernel(
                 // MFMA -> VALU read needs 18 wait states; hipcc pads for its own instructions but
                 // not for the inline-asm v_max_f64 below (tile a finished long ago, tile b has not)
                 __builtin_amdgcn_sched_barrier(0);
+                if constexpr (KS > 4) asm volatile("s_nop 15\n\ts_nop 3" ::: "memory");  // both tiles just issued
                 double ma[NF], mb[NF];
 #pragma unroll
                 for (int u = 0; u < NF; ++u) ma[u] = max_f64(max_f64(acca[u][0], acca[u][1]), max_f64(acca[u][2], acca[u][3]));
@@ -457,10 +521,12 @@ __global__ __launch_bounds__(kMT, kMT == 1024 ? 4 : 2) void kmeans_mfma_kernel(
                     const double m = max_f64(ma[u], mb[u]);
                     const bool better = m > best[u];  // strict: the first pair keeps ties
                     best[u] = better ? m : best[u];
-                    bpair[u] = better ? jt : bpair[u];
+                    const int code = kGlobalRecovery ? (((k0 >> 4) + jt) << 1) | (jb == jt ? 1 : 0) : jt;
+                    bpair[u] = better ? code : bpair[u];
                 }
             }
             KSTAMP(2);
+            if constexpr (!kGlobalRecovery) {
             // ---- winner of this chunk, per frame.  M = max over the frame's 4 lanes; the lane(s)
             // holding M name the pair; that pair's 8 candidate centres of the lane (2 tiles x 4
             // slots) are re-scored with the SAME chain, two per lane, and the lowest index with
@@ -506,8 +572,70 @@ __global__ __launch_bounds__(kMT, kMT == 1024 ? 4 : 2) void kmeans_mfma_kernel(
                     found = min(found, cand);
                     pending &= pending - 1;
                 }
-                // merge into the running winner over chunks (strict: the earlier chunk keeps ties)
-                if (M > bm[u] && found < k) { bm[u] = M; bidx[u] = found; }
+                if (found < k) { bm[u] = M; bidx[u] = found; }
+            }
+            }  // LDS recovery
+        }
+        if constexpr (kGlobalRecovery) {
+            // ---- winner over ALL chunks: the LDS tile has moved on, so the candidates of the winning
+            // pair are re-scored from the centre table in global memory (L2), and the frame is re-read
+            // instead of being gathered from registers: one plain loop over the features per tied lane.
+#pragma unroll
+            for (int u = 0; u < NF; ++u) {
+                double M = best[u];
+                M = fmax(M, __shfl_xor(M, 16, 64));
+                M = fmax(M, __shfl_xor(M, 32, 64));
+                const unsigned long long tied = __ballot(best[u] == M) >> j16;
+                unsigned pending = (unsigned)(tied & 1) | (unsigned)((tied >> 15) & 2) | (unsigned)((tied >> 30) & 4) |
+                                   (unsigned)((tied >> 45) & 8);
+                int found = 0x7fffffff;
+                const T* row = x + (fok[u] ? fidx[u] : 0) * ld;
+                while (__any(pending != 0)) {
+                    const int gs = pending ? __builtin_ctz(pending) : 0;
+                    const int pj = __shfl(bpair[u], j16 + 16 * gs, 64);
+                    const int ta = pj >> 1, tb = ta + ((pj & 1) ? 0 : 1);
+                    const int crow = gs + 4 * g;
+                    const int ia = ta * 16 + crow, ib = tb * 16 + crow;      // global centre indices
+                    const double* ca = centers + (size_t)min(ia, k - 1) * d;
+                    const double* cb = centers + (size_t)min(ib, k - 1) * d;
+                    double da = 0.0, db = 0.0;
+                    int f = 0;
+                    for (; f + 8 <= d; f += 8) {   // loads of 8 features in flight, FMAs in feature order
+                        double v[8], va[8], vb[8];
+#pragma unroll
+                        for (int q = 0; q < 8; ++q) {
+                            v[q] = load_as_f64(row + f + q);
+                            va[q] = ca[f + q];
+                            vb[q] = cb[f + q];
+                        }
+#pragma unroll
+                        for (int q = 0; q < 8; ++q) {
+                            double z = v[q];
+                            if (mean) z = (z - mean[f + q]) / stdv[f + q];
+                            da = fma(va[q], z, da);
+                            db = fma(vb[q], z, db);
+                        }
+                    }
+                    for (; f < d; ++f) {
+                        double v = load_as_f64(row + f);
+                        if (mean) v = (v - mean[f]) / stdv[f];
+                        da = fma(ca[f], v, da);
+                        db = fma(cb[f], v, db);
+                    }
+                    // fold: the spare k-slot contributes fma(-h, 1, .) = . - h; otherwise the VALU subtracts h
+                    da -= chalf_g[min(ia, k - 1)];
+                    db -= chalf_g[min(ib, k - 1)];
+                    int cand = 0x7fffffff;
+                    if (pending) {
+                        if (ib < k && db == M) cand = ib;
+                        if (ia < k && da == M) cand = ia;  // ia <= ib: the lower index last
+                    }
+                    cand = min(cand, __shfl_xor(cand, 16, 64));
+                    cand = min(cand, __shfl_xor(cand, 32, 64));
+                    found = min(found, cand);
+                    pending &= pending - 1;
+                }
+                if (found < k) { bm[u] = M; bidx[u] = found; }
             }
         }
         KSTAMP(3);
@@ -560,7 +688,7 @@ template <typename T, int KS, bool ACCUM>
 msm_status launch_mfma(msm_ctx* ctx, const T* x, int64_t n, int d, int64_t ld, const double* centers, int k,
                        const double* mean, const double* stdv, int32_t* labels, double* mindist, const FitState* st,
                        unsigned long long* sums, unsigned long long* counts) {
-    constexpr int NF = KS <= 8 ? 2 : 1;
+    constexpr int NF = KS <= 16 ? 2 : 1;
     constexpr int kMT = KS <= 4 ? kMTNarrow : kMTWide;
     constexpr int TS = KS * 64 + 1;  // doubles per 16-centre tile (see the kernel)
     const size_t acc_bytes = ACCUM ? (size_t)k * (d + 1) * sizeof(unsigned long long) : 0;
@@ -574,11 +702,23 @@ msm_status launch_mfma(msm_ctx* ctx, const T* x, int64_t n, int d, int64_t ld, c
     const int64_t n_units = (n + 16 * NF - 1) / (16 * NF);
     const int waves = kMT / 64;
     const int grid = (int)std::min<int64_t>((n_units + waves - 1) / waves, (int64_t)ctx->n_cu);
-    auto kern = (d & 3) != 0 ? kmeans_mfma_kernel<T, KS, NF, kMT, ACCUM, true> : kmeans_mfma_kernel<T, KS, NF, kMT, ACCUM, false>;
+    const bool multi = k > tile_k;
+    const bool foldm = (d & 3) != 0;
+    auto kern = multi ? (foldm ? kmeans_mfma_kernel<T, KS, NF, kMT, ACCUM, true, true>
+                               : kmeans_mfma_kernel<T, KS, NF, kMT, ACCUM, false, true>)
+                      : (foldm ? kmeans_mfma_kernel<T, KS, NF, kMT, ACCUM, true, false>
+                               : kmeans_mfma_kernel<T, KS, NF, kMT, ACCUM, false, false>);
+    double* chalf_g = nullptr;
+    if (multi || KS > 8) {   // the global winner recovery reads the half-norms from a table
+        msm_status rs = msm_reserve_aux(ctx, (size_t)k * sizeof(double));   // (the main scratch may hold the
+        if (rs != MSM_OK) return rs;                                        //  caller's member sums)
+        chalf_g = (double*)ctx->aux;
+        hipLaunchKernelGGL(chalf_kernel, dim3((k + 255) / 256), dim3(256), 0, ctx->stream, centers, k, d, chalf_g);
+    }
     if (lds > 48 * 1024)
         MSM_HIP(ctx, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(kern, dim3(grid), dim3(kMT), lds, ctx->stream, x, n, d, ld, centers, k, mean, stdv, tile_k,
-                       labels, mindist, st, sums, counts, lds_acc);
+                       labels, mindist, st, sums, counts, lds_acc, (const double*)chalf_g);
     MSM_CHECK_LAUNCH(ctx);
     return MSM_OK;
 }

@@ -5,8 +5,9 @@
 #include <vector>
 #include <cstdio>
 #include <cmath>
-int main() {
-    const int64_t n = 1000000; const int d = 10, k = 500;
+#include <cstdlib>
+int main(int argc, char** argv) {
+    const int64_t n = argc > 1 ? atoll(argv[1]) : 1000000; const int d = argc > 2 ? atoi(argv[2]) : 10, k = argc > 3 ? atoi(argv[3]) : 500;
     msm_ctx* ctx; if (msm_ctx_create(0, nullptr, &ctx)) return 1;
     std::vector<double> Y(n * d);
     unsigned long long sd = 12345;
@@ -29,9 +30,9 @@ int main() {
     }
     unsigned long long st[8];
     hipMemcpyFromSymbol(st, HIP_SYMBOL(g_km_stamps), sizeof(st));
-    const char* names[] = {"stage centres", "convert + prefetch issue", "tile loop", "select + merge", "accumulate (LDS atomics)", "barrier before flush", "flush", "loop exit"};
+    const char* names[] = {"stage centres", "convert + prefetch issue", "tile loop", "select + merge", "accumulate (LDS atomics)", "chunk staging | flush barrier", "flush", "loop exit"};
     unsigned long long tot = 0; for (int i = 0; i < 8; ++i) tot += st[i];
-    printf("kernel %.3f ms; stamps are sums over %d blocks (wave 0)\n", ms, 256);
+    printf("n=%lld d=%d k=%d kernel %.3f ms; stamps are sums over the blocks (wave 0)\n", (long long)n, d, k, ms);
     for (int i = 0; i < 8; ++i) printf("%-28s %12llu ticks  %5.1f%%  per block %.0f\n", names[i], st[i], 100.0 * st[i] / tot, st[i] / 256.0);
     printf("total per block %.0f ticks -> %.3f ms kernel => tick rate %.1f MHz\n", tot / 256.0, ms, tot / 256.0 / ms / 1e3);
     return 0;
