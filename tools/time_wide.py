@@ -9,7 +9,7 @@ from tools.time_kernels import timeit  # noqa: E402
 
 eng = Engine(0)
 rng = np.random.default_rng(0)
-for n, d, k in ((200_000, 256, 2000), (400_000, 64, 1000), (500_000, 32, 500), (1_000_000, 16, 500), (1_000_000, 10, 500)):
+for n, d, k in ((1_000_000, 10, 2000), (1_000_000, 4, 100), (200_000, 256, 2000), (400_000, 64, 1000), (500_000, 32, 500), (1_000_000, 16, 500), (1_000_000, 10, 500)):
     X = rng.normal(size=(n, d)).astype(np.float32)
     xd = eng.to_device(X)
     cen = eng.to_device(X[rng.choice(n, k, replace=False)].astype(np.float64))
