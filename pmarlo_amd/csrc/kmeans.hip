@@ -270,6 +270,41 @@ __global__ void chalf_kernel(const double* __restrict__ centers, int k, int d, d
     out[j] = 0.5 * a;
 }
 
+// Chunked launches: the LDS image of every 16-centre tile (k-step major, fold slot, one padding
+// double -- exactly what the tile loop reads) is built ONCE per launch in global memory, so that
+// staging a chunk is a straight 16-byte-vector copy.  img[t][TS], half[k16] (+inf for padding).
+template <int KS, bool FOLD>
+__global__ void pack_tiles_kernel(const double* __restrict__ centers, int k, int d, double* __restrict__ img,
+                                  double* __restrict__ half) {
+    constexpr int TS = KS * 64 + 1;
+    const int t = blockIdx.x;                    // tile
+    __shared__ double h[16];
+    const int lane = threadIdx.x;                // 64 threads
+    if (lane < 16) {
+        const int j = t * 16 + lane;
+        double a = 0.0;
+        if (j < k)
+            for (int f = 0; f < d; ++f) {
+                const double c = centers[(size_t)j * d + f];
+                a = fma(c, c, a);
+            }
+        h[lane] = j < k ? 0.5 * a : __builtin_inf();
+        half[j] = h[lane];
+    }
+    __syncthreads();
+    const int fold_s = d >> 2, fold_g = d & 3;
+    for (int rem = lane; rem < TS; rem += 64) {
+        double v = 0.0;
+        if (rem < KS * 64) {
+            const int s = rem >> 6, gg = (rem >> 4) & 3, jj = rem & 15;
+            const int j = t * 16 + jj, f = 4 * s + gg;
+            if (j < k && f < d) v = centers[(size_t)j * d + f];
+            if (FOLD && s == fold_s && gg == fold_g) v = -h[jj];
+        }
+        img[(size_t)t * TS + rem] = v;
+    }
+}
+
 // MULTI: the centres do not fit one LDS tile and are staged chunk by chunk (k > tile_k).
 template <typename T, int KS, int NF, int kMT, bool ACCUM, bool FOLD, bool MULTI>
 __global__ __launch_bounds__(kMT, kMT == 1024 ? 4 : 2) void kmeans_mfma_kernel(
@@ -277,7 +312,8 @@ __global__ __launch_bounds__(kMT, kMT == 1024 ? 4 : 2) void kmeans_mfma_kernel(
     const double* __restrict__ mean, const double* __restrict__ stdv, int tile_k /* multiple of 16 */,
     int32_t* __restrict__ labels, double* __restrict__ mindist, const FitState* __restrict__ st,
     unsigned long long* __restrict__ sums, unsigned long long* __restrict__ counts, int lds_acc,
-    const double* __restrict__ chalf_g /* [k] when MULTI or KS > 8 */) {
+    const double* __restrict__ chalf_g /* [k] when MULTI or KS > 8 */,
+    const double* __restrict__ tile_img /* packed tile images when MULTI */) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     // centre tile, k-step major so that a wave's A read is one contiguous 512-byte run:
     // cs[(j / 16) * TS + s * 64 + g * 16 + (j % 16)] = C[k0 + j][4s + g].  The tile stride TS
@@ -308,8 +344,27 @@ __global__ __launch_bounds__(kMT, kMT == 1024 ? 4 : 2) void kmeans_mfma_kernel(
     // stage centre tile [k0, k0 + kt): coordinates, then |c|^2/2 (ascending-feature FMA chain),
     // then (fold) the spare slot
     auto stage_tile = [&](int k0, int kt, int kt16) {
-        // 8 independent loads in flight per thread (the chunked case restages every frame round: a
-        // one-load-per-trip loop spent most of its time waiting on L2)
+        if constexpr (MULTI) {
+            // straight copy of the pre-packed images (pack_tiles_kernel): 16-byte vectors, four in
+            // flight per thread; the chunk starts at a multiple of 16 centres
+            const int n_doubles = (kt16 / 16) * TS;
+            const double* src = tile_img + (size_t)(k0 / 16) * TS;
+            const bool al = ((reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(cs)) & 15) == 0;
+            const int nvec = al ? n_doubles / 2 : 0;
+            const double2* s2 = reinterpret_cast<const double2*>(src);
+            double2* d2 = reinterpret_cast<double2*>(cs);
+            int i = tid;
+            for (; i + 3 * kMT < nvec; i += 4 * kMT) {
+                const double2 a = s2[i], b = s2[i + kMT], c = s2[i + 2 * kMT], e = s2[i + 3 * kMT];
+                d2[i] = a; d2[i + kMT] = b; d2[i + 2 * kMT] = c; d2[i + 3 * kMT] = e;
+            }
+            for (; i < nvec; i += kMT) d2[i] = s2[i];
+            for (int q = 2 * nvec + tid; q < n_doubles; q += kMT) cs[q] = src[q];
+            for (int j = tid; j < kt16; j += kMT) chalf[j] = chalf_g[k0 + j];
+            __syncthreads();
+            return;
+        }
+        // 8 independent loads in flight per thread
         const int total = kt16 * 4 * KS;
         for (int i0 = tid; i0 < total; i0 += 8 * kMT) {
             double v[8];
@@ -335,15 +390,12 @@ __global__ __launch_bounds__(kMT, kMT == 1024 ? 4 : 2) void kmeans_mfma_kernel(
             double* cj = cs + (j >> 4) * TS + (j & 15);
             double h = __builtin_inf();  // padding centres can never win
             if (j < kt) {
-                if constexpr (MULTI) h = chalf_g[k0 + j];
-                else {
-                    double a = 0.0;
-                    for (int f = 0; f < d; ++f) {
-                        const double c = cj[(f >> 2) * 64 + (f & 3) * 16];
-                        a = fma(c, c, a);
-                    }
-                    h = 0.5 * a;
+                double a = 0.0;
+                for (int f = 0; f < d; ++f) {
+                    const double c = cj[(f >> 2) * 64 + (f & 3) * 16];
+                    a = fma(c, c, a);
                 }
+                h = 0.5 * a;
             }
             chalf[j] = h;
             if (fold) cj[fold_s * 64 + fold_g * 16] = -h;
@@ -698,6 +750,9 @@ msm_status launch_mfma(msm_ctx* ctx, const T* x, int64_t n, int d, int64_t ld, c
     const int k16 = (k + 15) & ~15;
     if (tile_k > k16) tile_k = k16;
     if (tile_k < 16) tile_k = 16;
+    // chunked launches: an even number of tiles per chunk keeps every chunk of the packed image
+    // (odd tile stride TS) 16-byte aligned for the vector copy
+    if (tile_k < k16 && tile_k >= 32) tile_k &= ~31;
     const size_t lds = (size_t)(tile_k / 16) * (TS + 16) * sizeof(double) + (lds_acc ? acc_bytes : 0);
     const int64_t n_units = (n + 16 * NF - 1) / (16 * NF);
     const int waves = kMT / 64;
@@ -709,16 +764,31 @@ msm_status launch_mfma(msm_ctx* ctx, const T* x, int64_t n, int d, int64_t ld, c
                       : (foldm ? kmeans_mfma_kernel<T, KS, NF, kMT, ACCUM, true, false>
                                : kmeans_mfma_kernel<T, KS, NF, kMT, ACCUM, false, false>);
     double* chalf_g = nullptr;
-    if (multi || KS > 8) {   // the global winner recovery reads the half-norms from a table
-        msm_status rs = msm_reserve_aux(ctx, (size_t)k * sizeof(double));   // (the main scratch may hold the
-        if (rs != MSM_OK) return rs;                                        //  caller's member sums)
+    double* tile_img = nullptr;
+    if (multi) {   // packed tile images + half-norms, once per launch (the main scratch may hold the
+                   // caller's member sums, hence the auxiliary buffer)
+        const size_t n_tiles_all = (size_t)k16 / 16;
+        const size_t img_doubles = (n_tiles_all * TS + 1) & ~(size_t)1;
+        msm_status rs = msm_reserve_aux(ctx, (img_doubles + k16) * sizeof(double));
+        if (rs != MSM_OK) return rs;
+        tile_img = (double*)ctx->aux;
+        chalf_g = tile_img + img_doubles;
+        if (foldm)
+            hipLaunchKernelGGL((pack_tiles_kernel<KS, true>), dim3((unsigned)n_tiles_all), dim3(64), 0, ctx->stream, centers,
+                               k, d, tile_img, chalf_g);
+        else
+            hipLaunchKernelGGL((pack_tiles_kernel<KS, false>), dim3((unsigned)n_tiles_all), dim3(64), 0, ctx->stream, centers,
+                               k, d, tile_img, chalf_g);
+    } else if (KS > 8) {   // the global winner recovery reads the half-norms from a table
+        msm_status rs = msm_reserve_aux(ctx, (size_t)k * sizeof(double));
+        if (rs != MSM_OK) return rs;
         chalf_g = (double*)ctx->aux;
         hipLaunchKernelGGL(chalf_kernel, dim3((k + 255) / 256), dim3(256), 0, ctx->stream, centers, k, d, chalf_g);
     }
     if (lds > 48 * 1024)
         MSM_HIP(ctx, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(kern, dim3(grid), dim3(kMT), lds, ctx->stream, x, n, d, ld, centers, k, mean, stdv, tile_k,
-                       labels, mindist, st, sums, counts, lds_acc, (const double*)chalf_g);
+                       labels, mindist, st, sums, counts, lds_acc, (const double*)chalf_g, (const double*)tile_img);
     MSM_CHECK_LAUNCH(ctx);
     return MSM_OK;
 }
