@@ -211,7 +211,9 @@ msm_status msm_standardise_params(msm_ctx* ctx, const double* d_sums, const doub
  * (they must share d_shift).  At most 16 segments per call.  F <= 64 runs the fused
  * single-pass kernel; larger F the 64 x 64 block-task kernel.
  * assume_finite != 0 skips the NaN test (callers know from msm_column_moments'
- * d_count whether X holds NaNs; with NaNs present it must be 0). */
+ * d_count whether X holds NaNs; with NaNs present it must be 0).
+ * lag == 0 gives the instantaneous second moments (M00 = 2 sum z z', T = n): the covariance
+ * behind pca_reduce (S/markov_state_model/reduction.py:43-74). */
 msm_status msm_lagged_moments(msm_ctx* ctx, const void* d_x, msm_dtype dtype, int64_t n, int F, int64_t ld,
                               const int64_t* h_seg_start, const int64_t* h_seg_stop, int n_seg, int lag,
                               const double* d_shift, int assume_finite, double* d_moments);

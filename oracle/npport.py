@@ -703,3 +703,20 @@ def macro_mfpt(T_macro):
             t = np.full(n - 1, np.nan)
         out[mask, j] = t
     return out
+
+
+# ---------------------------------------------------------------------------
+# PCA (S/markov_state_model/reduction.py:43-74: _preprocess + sklearn PCA; pinned by tests/golden/pca.npz)
+# ---------------------------------------------------------------------------
+def pca_reduce(X, n_components=2, scale=True):
+    """Covariance-eigh PCA as sklearn >= 1.5 runs it for tall matrices: ddof = 1, descending variance,
+    every component's largest-magnitude loading positive (svd_flip on V)."""
+    Z = preprocess(X, scale=scale)
+    Zc = Z - Z.mean(axis=0)
+    C = Zc.T @ Zc / max(Z.shape[0] - 1, 1)
+    w, V = np.linalg.eigh(C)
+    order = np.argsort(-w, kind="stable")[:n_components]
+    comps = V[:, order]
+    top = np.argmax(np.abs(comps), axis=0)
+    comps = comps * np.sign(comps[top, np.arange(comps.shape[1])])[None, :]
+    return Zc @ comps

@@ -521,7 +521,7 @@ msm_status launch_cov_blocked(msm_ctx* ctx, const T* x, int F, int64_t ld, const
 
 msm_status build_frametab(msm_ctx* ctx, int64_t n, const int64_t* h_start, const int64_t* h_stop, int n_seg, int lag,
                           FrameTab* out) {
-    MSM_REQUIRE(ctx, lag >= 1, "lag must be >= 1 (got %d)", lag);
+    MSM_REQUIRE(ctx, lag >= 0, "lag must be >= 0 (got %d)", lag);   // 0: instantaneous covariance (PCA)
     FrameTab ft;
     memset(&ft, 0, sizeof(ft));
     ft.lag = lag;

@@ -4,14 +4,14 @@ and of FeaturesMixin._maybe_apply_tica (S/markov_state_model/_features.py:181-23
 
 from __future__ import annotations
 
-from typing import List, Sequence
+from typing import Optional, List, Sequence
 
 import numpy as np
 
 from ..device import get_engine
 from ..pipeline import MSMPipeline, TicaModel
 
-__all__ = ["tica_reduce", "reduce_features", "tica_fit_transform_trajectories", "preprocess_params"]
+__all__ = ["tica_reduce", "pca_reduce", "reduce_features", "tica_fit_transform_trajectories", "preprocess_params"]
 
 
 def _as_matrix(X) -> np.ndarray:
@@ -49,13 +49,54 @@ def tica_reduce(X: np.ndarray, lag: int = 1, n_components: int = 2, scale: bool 
     return np.ascontiguousarray(pipe.tica_transform(model, xd).to_host(), dtype=float)
 
 
-def reduce_features(X: np.ndarray, method: str = "tica", n_components: int = 2, lag: int = 1, scale: bool = True,
+def pca_reduce(X: np.ndarray, n_components: int = 2, batch_size: Optional[int] = None, scale: bool = True) -> np.ndarray:
+    """_preprocess + sklearn PCA(n_components).fit_transform (S/markov_state_model/reduction.py:43-74) on the
+    GPU: second moments on the matrix cores (lag 0), Jacobi eigendecomposition of the F x F covariance
+    (sklearn's covariance_eigh solver: ddof = 1, components by descending variance, each component's
+    largest-magnitude loading made positive), projection on the matrix cores.  ``batch_size``
+    (IncrementalPCA) is not available."""
+    if batch_size is not None:
+        raise NotImplementedError("IncrementalPCA (batch_size) is outside the accelerated path")
+    Xm = _as_matrix(X)
+    n, F = Xm.shape
+    n_components = int(n_components)
+    if not 1 <= n_components <= min(n, F):
+        raise ValueError(f"n_components={n_components} must be between 1 and min(n_samples, n_features)={min(n, F)}")
+    eng = get_engine()
+    pipe = MSMPipeline(eng)
+    xd = eng.to_device(Xm)
+    mu, sigma, inv_sigma, has_nan = pipe.standardise_params(xd, scale=scale)
+    mom = pipe.tica_moments(xd, 0, mu, assume_finite=not has_nan).to_host()
+    sd = sigma.to_host()
+    S = 0.5 * mom[:F * F].reshape(F, F)                      # sum (x - mu)(x - mu)'
+    delta = mom[2 * F * F:2 * F * F + F] / float(n)          # residual mean of the centred data (~1e-17)
+    C = (S - n * np.outer(delta, delta)) / np.outer(sd, sd) / max(n - 1, 1)
+    C = 0.5 * (C + C.T)
+    w, V, _ = eng.eigh(eng.to_device(C))
+    w, V = w.to_host(), V.to_host()
+    order = np.argsort(-w, kind="stable")[:n_components]
+    comps = V[:, order]
+    top = np.argmax(np.abs(comps), axis=0)
+    comps = comps * np.sign(comps[top, np.arange(comps.shape[1])])[None, :]
+    Wfull = np.zeros((F, F))
+    Wfull[:, :n_components] = comps
+    # z - mean(z): the preprocessed columns are centred up to rounding; fold the residual in as mean2
+    mean2 = eng.to_device(delta / sd)
+    Y = eng.project(xd, mu, inv_sigma, eng.to_device(Wfull), n_components, mean2=mean2)
+    return np.asarray(Y.to_host(), dtype=float)
+
+
+def reduce_features(X: np.ndarray, method: str = "pca", n_components: int = 2, lag: int = 1, scale: bool = True,
                     **kwargs) -> np.ndarray:
-    method = method.lower()
+    """Unified interface (reduction.py:152-197): "pca" (default, as in the reference), "tica"; "vamp" needs
+    deeptime's estimator and is not available."""
+    method = str(method).lower()
+    if method == "pca":
+        return pca_reduce(X, n_components=n_components, scale=scale, **kwargs)
     if method == "tica":
         return tica_reduce(X, lag=lag, n_components=n_components, scale=scale, **kwargs)
-    if method in ("pca", "vamp"):
-        raise NotImplementedError(f"{method!r} is outside the accelerated path (TICA only)")
+    if method == "vamp":
+        raise NotImplementedError("'vamp' is outside the accelerated path (PCA and TICA only)")
     raise ValueError(f"Unknown reduction method: {method}")
 
 

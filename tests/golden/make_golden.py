@@ -290,6 +290,18 @@ def golden_ck():
     np.savez_compressed(OUT / "ck.npz", **out)
 
 
+def golden_pca():
+    """reduction.pca_reduce (sklearn PCA behind _preprocess), scale on / off, with missing values."""
+    from pmarlo.markov_state_model.reduction import pca_reduce as ref_pca
+
+    X = correlated_series(3000, 12, seed=31).astype(np.float64) * np.linspace(0.5, 3.0, 12)[None, :]
+    X[np.random.default_rng(5).random(X.shape) < 0.004] = np.nan
+    out = {"X": X}
+    for name, kw in (("scaled", dict(n_components=3, scale=True)), ("raw", dict(n_components=5, scale=False))):
+        out[f"{name}_Y"] = ref_pca(X.copy(), **kw)
+    np.savez_compressed(OUT / "pca.npz", **out)
+
+
 def golden_fes():
     """analysis/fes.py: compute_weighted_fes, grid and KDE, weighted and not (whitening off: the
     dataset carries no DeepTICA metadata)."""
@@ -331,6 +343,7 @@ def golden_fes():
 
 
 if __name__ == "__main__":
+    golden_pca()
     golden_fes()
     golden_ck()
     golden_counts()
