@@ -268,6 +268,7 @@ msm_status msm_graph_end(msm_ctx* ctx, msm_graph** out) {
     hipError_t e = hipStreamEndCapture(ctx->stream, &g->graph);
     if (e != hipSuccess || !g->graph) {
         delete g;
+        (void)hipGetLastError();  // an invalidated capture leaves a sticky error behind
         return msm_fail(ctx, MSM_ERR_HIP, "hipStreamEndCapture: %s", hipGetErrorString(e));
     }
     e = hipGraphInstantiate(&g->exec, g->graph, nullptr, nullptr, 0);
