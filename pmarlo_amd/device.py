@@ -630,13 +630,18 @@ class Engine:
             p = min(32, max(n_its + 1 + 6, 8))
         p = int(min(p, 32, k))
         ws_bytes = int(lib.msm_spectrum_workspace_bytes(k, p, B))
-        ws = self.empty((ws_bytes,), np.uint8)
-        ritz = self.empty((B, 128), np.float64)
+        # the solver's buffers are kept between calls of the same shape (a lag scan calls this once
+        # per estimate; nine hipMallocs cost more than the solve of a small matrix); pi is returned
+        # to the caller and therefore always fresh
+        cache = getattr(self, "_spec_cache", None)
+        key = (k, B, max(n_its, 1))
+        if cache is None or cache[0] != key or cache[1].size < ws_bytes:
+            cache = (key, self.empty((ws_bytes,), np.uint8), self.empty((B, 128), np.float64),
+                     self.empty((B,), np.float64), self.empty((B,), np.int32),
+                     self.empty((B, max(n_its, 1)), np.float64), self.empty((B, max(n_its, 1)), np.float64))
+            self._spec_cache = cache
+        _, ws, ritz, change, status, its_eig, its_ts = cache
         pi = self.empty((B, k), np.float64) if want_pi else None
-        change = self.empty((B,), np.float64)
-        status = self.empty((B,), np.int32)
-        its_eig = self.empty((B, max(n_its, 1)), np.float64)
-        its_ts = self.empty((B, max(n_its, 1)), np.float64)
         lag_d = self.to_device(np.asarray(lags if lags is not None else np.ones(B), np.float64).reshape(B))
         launches = 0
         restart = True
@@ -658,6 +663,7 @@ class Engine:
             if since_restart >= 8 and p < min(32, k):
                 p = int(min(32, k, 2 * p))
                 ws = self.empty((int(lib.msm_spectrum_workspace_bytes(k, p, B)),), np.uint8)
+                self._spec_cache = (key, ws, ritz, change, status, its_eig, its_ts)
                 restart, since_restart = True, 0
         else:
             if not allow_unconverged:
