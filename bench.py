@@ -71,6 +71,8 @@ def main() -> None:
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-single-thread", action="store_true",
+                    help="also time the CPU restatement pinned to one thread on the full shard (about a minute)")
     ap.add_argument("--frames", type=int, default=N_FRAMES, help="frames per GPU (default: the BASELINE config)")
     args = ap.parse_args()
 
@@ -235,6 +237,14 @@ def main() -> None:
             got = np.asarray(parity.get("tica_eigenvalues", ref_eig))
             out["parity"]["tica_eig_rel_err"] = float(np.max(np.abs(got - ref_eig) / np.abs(ref_eig)))
             out["cpu_baseline"] = cb
+            if args.cpu_single_thread:
+                from threadpoolctl import threadpool_limits
+
+                with threadpool_limits(limits=1):
+                    cb1 = cpu_baseline(X)
+                cb1.pop("tica_eigenvalues", None)
+                cb1["cores"] = 1
+                out["cpu_baseline_1thread"] = cb1
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out), flush=True)
