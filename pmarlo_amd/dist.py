@@ -65,14 +65,16 @@ class TorchComm(Comm):
         # (these buffers are <= a few hundred KB: latency-bound either way)
         import torch
 
-        parts = self._gather.get(name)
-        if parts is None:
-            parts = [torch.empty_like(t) for _ in range(self.world)]
-            self._gather[name] = parts
-        self.dist.all_gather(parts, t)
-        t.copy_(parts[0])
-        for r in range(1, self.world):
-            t.add_(parts[r])
+        buf = self._gather.get(name)
+        if buf is None:
+            buf = torch.empty((self.world,) + tuple(t.shape), dtype=t.dtype, device=t.device)
+            self._gather[name] = buf
+        if self.dist.get_backend() == "nccl":
+            self.dist.all_gather_into_tensor(buf, t)            # one RCCL call, no per-rank tensor list
+        else:
+            self.dist.all_gather([buf[r] for r in range(self.world)], t)
+        # fixed-order sum over the rank axis: one kernel, no atomics, the same bits on every rank
+        torch.sum(buf, dim=0, out=t)
 
     def allreduce_min(self, name):
         self.dist.all_reduce(self.t[name], op=self.dist.ReduceOp.MIN)
