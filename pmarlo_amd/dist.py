@@ -53,6 +53,7 @@ class TorchComm(Comm):
         self.world = dist.get_world_size()
         self.rank = dist.get_rank()
         self._gather: dict = {}
+        self._into_tensor = dist.get_backend() == "nccl"
 
     def allreduce_sum(self, name):
         t = self.t[name]
@@ -69,9 +70,14 @@ class TorchComm(Comm):
         if buf is None:
             buf = torch.empty((self.world,) + tuple(t.shape), dtype=t.dtype, device=t.device)
             self._gather[name] = buf
-        if self.dist.get_backend() == "nccl":
-            self.dist.all_gather_into_tensor(buf, t)            # one RCCL call, no per-rank tensor list
-        else:
+        done = False
+        if self._into_tensor:
+            try:
+                self.dist.all_gather_into_tensor(buf, t)        # one RCCL call, no per-rank tensor list
+                done = True
+            except (RuntimeError, NotImplementedError, AttributeError):
+                self._into_tensor = False                       # backend without the fused form (refused up front)
+        if not done:
             self.dist.all_gather([buf[r] for r in range(self.world)], t)
         # fixed-order sum over the rank axis: one kernel, no atomics, the same bits on every rank
         torch.sum(buf, dim=0, out=t)
