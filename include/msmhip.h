@@ -458,6 +458,20 @@ msm_status msm_macro_mfpt(msm_ctx* ctx, const double* d_T, int64_t ldt, int n, d
 msm_status msm_silhouette(msm_ctx* ctx, const double* d_x, int64_t n, int d, int64_t ld,
                           const int64_t* h_offsets, int k, double* d_samples, double* d_score);
 
+/* ---- regular-grid microstates (cluster_mode = "grid") -----------------------------------------
+ * Replaces _GridDiscretizer._compute_indices / transform (S/analysis/discretize.py:552-583).
+ * msm_grid_cells: d_flat[t] = sum_f idx_f * bins^(F-1-f), idx_f = clip(np.digitize(x[t][f],
+ *   edges_f) - 1, 0, bins - 1); d_edges f64 [F][bins + 1] increasing; NaN -> last bin (as numpy).
+ * msm_first_occurrence: d_first[c] = smallest frame index t with d_flat[t] == c, or -1 (the
+ *   reference numbers states by order of first appearance).
+ * msm_relabel: d_labels[t] = d_map[d_flat[t]]. */
+msm_status msm_grid_cells(msm_ctx* ctx, const void* d_x, msm_dtype dtype, int64_t n, int F, int64_t ld,
+                          const double* d_edges, int bins, int32_t* d_flat);
+msm_status msm_first_occurrence(msm_ctx* ctx, const int32_t* d_flat, int64_t n, int n_cells,
+                                int64_t* d_first);
+msm_status msm_relabel(msm_ctx* ctx, const int32_t* d_flat, int64_t n, const int32_t* d_map, int n_cells,
+                       int32_t* d_labels);
+
 #ifdef __cplusplus
 }
 #endif

@@ -720,3 +720,46 @@ def pca_reduce(X, n_components=2, scale=True):
     top = np.argmax(np.abs(comps), axis=0)
     comps = comps * np.sign(comps[top, np.arange(comps.shape[1])])[None, :]
     return Zc @ comps
+
+
+# ---- regular-grid microstates (S/analysis/discretize.py:517-593) ---------------------------------
+class GridStates:
+    """_GridDiscretizer restated: per-feature equal-width edges between the training extremes; a
+    frame's state is the rank of first appearance of its bin combination, counted over fit() and
+    then every transform() call in order."""
+
+    def __init__(self, target_states):
+        self.target_states = max(int(target_states), 1)
+        self.edges = []
+        self.mapping = {}
+
+    def cells(self, X):
+        cols = []
+        for f, e in enumerate(self.edges):
+            cols.append(np.clip(np.digitize(X[:, f], e) - 1, 0, len(e) - 2))
+        return np.stack(cols, axis=1)
+
+    def fit(self, X):
+        F = X.shape[1]
+        bins = max(int(round(self.target_states ** (1.0 / F))), 1)
+        self.edges = []
+        for f in range(F):
+            lo, hi = float(np.min(X[:, f])), float(np.max(X[:, f]))
+            if not (np.isfinite(lo) and np.isfinite(hi)):
+                raise ValueError("Non-finite values encountered while building grid")
+            if lo == hi:
+                lo, hi = lo - 0.5, hi + 0.5
+            self.edges.append(np.linspace(lo, hi, bins + 1, dtype=np.float64))
+        for row in self.cells(X):
+            self.mapping.setdefault(tuple(int(v) for v in row), len(self.mapping))
+        return self
+
+    def transform(self, X):
+        out = np.empty(X.shape[0], dtype=np.int32)
+        for i, row in enumerate(self.cells(X)):
+            out[i] = self.mapping.setdefault(tuple(int(v) for v in row), len(self.mapping))
+        return out
+
+    def centers(self):
+        mesh = np.meshgrid(*[(e[:-1] + e[1:]) / 2.0 for e in self.edges], indexing="ij")
+        return np.stack([m.ravel() for m in mesh], axis=1)

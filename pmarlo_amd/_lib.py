@@ -93,6 +93,9 @@ _PROTOTYPES: dict[str, tuple] = {
     "msm_lump_macro": (_i32, [_vp, _vp, _i64, _vp, _vp, _i32, _i32, _vp, _vp]),
     "msm_macro_mfpt": (_i32, [_vp, _vp, _i64, _i32, _vp, _vp]),
     "msm_silhouette": (_i32, [_vp, _vp, _i64, _i32, _i64, _vp, _i32, _vp, _vp]),
+    "msm_grid_cells": (_i32, [_vp, _vp, _i32, _i64, _i32, _i64, _vp, _i32, _vp]),
+    "msm_first_occurrence": (_i32, [_vp, _vp, _i64, _i32, _vp]),
+    "msm_relabel": (_i32, [_vp, _vp, _i64, _vp, _i32, _vp]),
     "msm_ck_test": (_i32, [_vp, _vp, _i64, _vp, _i64, _i64, _i32, _vp, _i32, _vp, _i64, _vp, _vp]),
 }
 

@@ -20,7 +20,7 @@ from .validation import validate_features
 logger = logging.getLogger("pmarlo")
 DatasetLike = Mapping[str, Any] | MutableMapping[str, Any]
 
-__all__ = ["MSMDiscretizationResult", "NoAssignmentsError", "discretize_dataset", "KMeansDiscretizer"]
+__all__ = ["MSMDiscretizationResult", "NoAssignmentsError", "discretize_dataset", "KMeansDiscretizer", "GridDiscretizer"]
 
 
 @dataclass(slots=True)
@@ -288,6 +288,81 @@ class KMeansDiscretizer:
         return {"mean": self.scaler_mean_.tolist(), "std": self.scaler_std_.tolist(), "enabled": True}
 
 
+class GridDiscretizer:
+    """_GridDiscretizer (S/analysis/discretize.py:517-593): ``round(target ** (1/F))`` equal-width bins per
+    feature between the training minimum and maximum; a frame's state is the order of first appearance
+    of its bin combination (training frames first, then every transformed split in call order)."""
+
+    _MAX_CELLS = 1 << 24
+
+    def __init__(self, *, target_states: int) -> None:
+        self.target_states = max(int(target_states), 1)
+        self.edges: list[np.ndarray] = []
+        self.feature_schema: Dict[str, Any] | None = None
+        self._cell_map: np.ndarray | None = None     # cell -> state, -1 = not seen yet
+        self._n_states = 0
+        self._bins = 0
+        self._eng = get_engine()
+
+    def _assign_new_states(self, flat_d, n_cells: int) -> None:
+        first = self._eng.first_occurrence(flat_d, n_cells)
+        unseen = np.nonzero((first >= 0) & (self._cell_map < 0))[0]
+        for cell in unseen[np.argsort(first[unseen], kind="stable")]:
+            self._cell_map[cell] = self._n_states
+            self._n_states += 1
+
+    def fit(self, X: np.ndarray, feature_schema: Mapping[str, Any] | None = None) -> None:
+        n, F = X.shape
+        schema = dict(feature_schema or {})
+        if int(schema.get("n_features", F)) != F:
+            raise ValueError(f"Feature schema reports {schema.get('n_features')} features, but training data has {F}")
+        names = list(schema.get("names") or [])
+        schema["names"] = [str(v) for v in names] if names else [f"feature_{i}" for i in range(F)]
+        schema["n_features"] = F
+        self.feature_schema = schema
+        bins = max(int(round(self.target_states ** (1.0 / F))), 1)
+        if float(bins) ** F > self._MAX_CELLS:
+            raise NotImplementedError(f"grid of {bins}^{F} cells is too large for the device table")
+        eng = self._eng
+        xd = eng.to_device(np.ascontiguousarray(X, np.float64))
+        self.edges = []
+        for col in range(F):
+            st = eng.weighted_stats(xd, col)          # [., ., ., ., min, max]; NaN / inf propagate into the sum
+            lo, hi = float(st[4]), float(st[5])
+            if not np.isfinite(st[2]) or not np.isfinite(lo) or not np.isfinite(hi):
+                raise ValueError("Non-finite values encountered while building grid")
+            if lo == hi:
+                lo, hi = lo - 0.5, hi + 0.5
+            self.edges.append(np.linspace(lo, hi, bins + 1, dtype=np.float64))
+        self._bins = bins
+        n_cells = bins ** F
+        self._cell_map = np.full(n_cells, -1, dtype=np.int32)
+        self._n_states = 0
+        self._assign_new_states(eng.grid_cells(xd, np.stack(self.edges)), n_cells)
+
+    def transform(self, X: np.ndarray, feature_schema: Mapping[str, Any] | None = None, *,
+                  split_name: str | None = None) -> np.ndarray:
+        if not self.edges:
+            raise RuntimeError("Discretizer has not been fitted")
+        if feature_schema is not None and self.feature_schema is not None:
+            _validate_feature_schema(self.feature_schema, feature_schema, split_name=split_name or "split")
+        eng = self._eng
+        flat = eng.grid_cells(eng.to_device(np.ascontiguousarray(X, np.float64)), np.stack(self.edges))
+        self._assign_new_states(flat, self._cell_map.size)      # combinations not seen before get new states
+        return eng.relabel(flat, self._cell_map).to_host()
+
+    @property
+    def centers(self) -> np.ndarray | None:
+        if not self.edges:
+            return None
+        mesh = np.meshgrid(*[(e[:-1] + e[1:]) / 2.0 for e in self.edges], indexing="ij")
+        return np.stack([m.ravel() for m in mesh], axis=1)
+
+    @property
+    def scaler_params(self) -> Dict[str, Any]:
+        return {}
+
+
 def _device_counts(labels: np.ndarray, n_states: int, lag: int, weights, segments):
     eng = get_engine()
     pipe = MSMPipeline(eng)
@@ -308,16 +383,18 @@ def discretize_dataset(dataset: DatasetLike, *, cluster_mode: str = "kmeans", n_
     fit so that results are reproducible against a reference fit (parity mode)."""
     if lag_time < 1:
         raise ValueError("lag_time must be >= 1")
-    if cluster_mode != "kmeans":
-        if cluster_mode == "grid":
-            raise NotImplementedError("cluster_mode='grid' is outside the accelerated path")
+    if cluster_mode not in ("kmeans", "grid"):
         raise ValueError("cluster_mode must be 'kmeans' or 'grid'")
     splits = _normalise_splits(dataset)
     train_key = "train" if "train" in splits else next(iter(splits))
     train_data = _coerce_array(splits[train_key])
     feature_schema = _extract_feature_schema(splits[train_key], train_data.shape[1])
     stats_by_split: Dict[str, Dict[str, Any]] = {train_key: validate_features(train_data, feature_schema["names"])}
-    disc = KMeansDiscretizer(n_microstates, random_state=random_state, apply_whitening=apply_whitening, centers=centers)
+    if cluster_mode == "grid":
+        disc = GridDiscretizer(target_states=n_microstates)
+    else:
+        disc = KMeansDiscretizer(n_microstates, random_state=random_state, apply_whitening=apply_whitening,
+                                 centers=centers)
     disc.fit(train_data, feature_schema)
     feature_schema = disc.feature_schema or feature_schema
     stats_by_split[train_key]["feature_names"] = list(feature_schema["names"])

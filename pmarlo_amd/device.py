@@ -506,6 +506,32 @@ class Engine:
               self.handle)
         return float(score.to_host()[0]), samples
 
+    # -- regular-grid microstates ---------------------------------------------------------------
+    def grid_cells(self, x: DeviceArray, edges: np.ndarray) -> DeviceArray:
+        """Flat cell index per frame for edges [F, bins + 1] (np.digitize - 1, clipped)."""
+        n, F = x.shape
+        e = np.ascontiguousarray(edges, np.float64)
+        if e.shape[0] != F:
+            raise ValueError("edges must have one row per feature")
+        flat = self.empty((n,), np.int32)
+        dt = _lib.MSM_F32 if x.dtype == np.float32 else _lib.MSM_F64
+        ed = self.to_device(e)
+        check(lib.msm_grid_cells(self.handle, x.ptr, dt, n, F, F, ed.ptr, e.shape[1] - 1, flat.ptr), self.handle)
+        self.sync()
+        return flat
+
+    def first_occurrence(self, flat: DeviceArray, n_cells: int) -> np.ndarray:
+        first = self.empty((int(n_cells),), np.int64)
+        check(lib.msm_first_occurrence(self.handle, flat.ptr, flat.size, int(n_cells), first.ptr), self.handle)
+        return first.to_host()
+
+    def relabel(self, flat: DeviceArray, cell_map: np.ndarray) -> DeviceArray:
+        m = self.to_device(np.ascontiguousarray(cell_map, np.int32))
+        labels = self.empty((flat.size,), np.int32)
+        check(lib.msm_relabel(self.handle, flat.ptr, flat.size, m.ptr, m.size, labels.ptr), self.handle)
+        self.sync()
+        return labels
+
     # -- dense solves on T: committors / flux / lumping / MFPT --------------------------------
     def solve(self, A: DeviceArray, B: DeviceArray) -> int:
         """A X = B in place (A -> LU factors, B -> X); returns 0 or the 1-based singular column."""

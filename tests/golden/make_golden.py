@@ -342,7 +342,43 @@ def golden_fes():
     np.savez_compressed(OUT / "fes.npz", **out)
 
 
+def golden_grid():
+    """_GridDiscretizer (analysis/discretize.py:517-593): first-appearance state numbering on a
+    regular grid; the test split reaches cells the training split never visits, a constant column
+    exercises the lo == hi branch, and values sit exactly on edges."""
+    rng = np.random.default_rng(23)
+    out = {}
+    train = rng.normal(size=(3000, 3)) * np.array([1.0, 2.0, 0.5])
+    train[:, 1] = np.round(train[:, 1], 1)
+    test = rng.normal(size=(800, 3)) * np.array([2.5, 4.0, 1.5])
+    test[::97, 0] = np.nan
+    test[5::131, 2] = np.inf
+    g = ref_disc._GridDiscretizer(target_states=60)
+    g.fit(train)
+    test[3::59, 0] = g.edges[0][2]          # exactly on an interior edge
+    test[7::61, 1] = g.edges[1][-1]         # exactly the training maximum
+    out.update(a_train=train, a_test=test, a_edges=np.stack(g.edges), a_lab_train=g.transform(train),
+               a_lab_test=g.transform(test), a_lab_train_again=g.transform(train), a_centers=g.centers,
+               a_n_states=np.int64(len(g.mapping)))
+    flat = rng.normal(size=(500, 2))
+    flat[:, 1] = 1.25
+    g2 = ref_disc._GridDiscretizer(target_states=25)
+    g2.fit(flat)
+    out.update(b_train=flat, b_edges=np.stack(g2.edges), b_lab=g2.transform(flat))
+    # whole entry point, grid mode
+    tr, _ = gaussian_clusters(5, 120, 3, 31)
+    tr = tr[np.argsort(rng.permutation(tr.shape[0]) // 40, kind="stable")]
+    va, _ = gaussian_clusters(5, 20, 3, 32)
+    ds = {"splits": {"train": {"X": tr}, "val": {"X": va * 1.5}}}
+    res = prepare_msm_discretization(ds, cluster_mode="grid", n_microstates=27, lag_time=2)
+    out.update(c_train=tr, c_val=va * 1.5, c_a_train=res.assignments["train"], c_a_val=res.assignments["val"],
+               c_counts=res.counts, c_T=res.transition_matrix, c_state_counts=res.state_counts,
+               c_centers=res.centers)
+    np.savez_compressed(OUT / "grid.npz", **out)
+
+
 if __name__ == "__main__":
+    golden_grid()
     golden_pca()
     golden_fes()
     golden_ck()
