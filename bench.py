@@ -79,7 +79,9 @@ def main() -> None:
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    multi = world > 1
+    # BENCH_FORCE_EXCHANGE=1 (under torch.distributed.run with one rank): keep every collective in the
+    # step, so a one-GPU box exercises the RCCL calls the N > 1 runs make
+    multi = world > 1 or os.environ.get("BENCH_FORCE_EXCHANGE") == "1"
     if args.gpus != world and rank == 0:
         print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
 
@@ -116,7 +118,7 @@ def main() -> None:
     if multi:
         tensors, shared = torch_exchange_buffers(eng, cfg, torch.device("cuda", local_rank))
         comm = TorchComm(tensors)
-    msm = ShardedMSM(eng, cfg, xd, comm=comm, shared=shared)
+    msm = ShardedMSM(eng, cfg, xd, comm=comm, shared=shared, always_exchange=multi)
 
     def barrier():
         eng.sync()
@@ -143,7 +145,7 @@ def main() -> None:
     # from-host pass: the same step with the shard uploaded from pageable host
     # memory inside the clock -- reported beside `value`, never as it
     from_host = None
-    if not multi:
+    if world == 1 and not multi:
         eng.sync()
         t1 = time.perf_counter()
         xd2 = eng.to_device(X)
@@ -184,7 +186,9 @@ def main() -> None:
                                    f"TICA->{TICA_DIM}, k={K_STATES} ({KMEANS_ITERS} Lloyd iterations), lag={LAG}, "
                                    "row-normalised T", "frames_per_gpu": n, "features": N_FEATURES,
                        "tica_dim": TICA_DIM, "k": K_STATES, "lag": LAG, "kmeans_iters": KMEANS_ITERS,
-                       "parallelism": f"shards{world}"},
+                       "parallelism": f"shards{world}",
+                       "exchange": ("rccl" if os.environ.get("BENCH_BACKEND", "nccl") == "nccl" else "gloo") if multi
+                       else None},
             "roofline": {"kernel": "kmeans_mfma_kernel<double,3,2,1024,true,true> (assign + accumulate)", "bound": "mfma",
                          "achieved": achieved_tf, "peak": FP64_MFMA_PEAK_TF, "unit": "TFLOP/s",
                          "frac": achieved_tf / FP64_MFMA_PEAK_TF,
@@ -201,7 +205,7 @@ def main() -> None:
             counts = msm.buf["counts"].view((K_STATES, K_STATES)).to_host()
             pairs = int(msm.buf["counts"].view((1,), offset_elems=K_STATES * K_STATES).to_host()[0])
             labels = msm.labels.to_host()
-            if not multi:
+            if world == 1:
                 want, pw = cport.count_transitions(labels, K_STATES, LAG)
                 parity["counts_bit_exact"] = bool(np.array_equal(counts, want) and pairs == pw)
                 want_lab = cport.kmeans_assign(msm.Y.to_host(), msm.buf["centers"].to_host())

@@ -128,9 +128,12 @@ class ShardedMSM:
     """featurised shard -> TICA -> k-means -> counts -> T, device resident, one step = one pass."""
 
     def __init__(self, engine: Engine, cfg: ShardConfig, x: DeviceArray, comm: Comm | None = None,
-                 shared: dict[str, DeviceArray] | None = None):
+                 shared: dict[str, DeviceArray] | None = None, always_exchange: bool = False):
         self.eng, self.cfg, self.x = engine, cfg, x
         self.comm = comm
+        # always_exchange: run every collective even in a group of one (rehearses the RCCL calls on a
+        # one-GPU box; a sum / min / broadcast over one rank leaves the buffers bit-identical)
+        self.always_exchange = bool(always_exchange) and comm is not None
         self.world = comm.world if comm else 1
         self.n_total = cfg.n_total if cfg.n_total is not None else cfg.n_frames * self.world
         eng = engine
@@ -157,14 +160,14 @@ class ShardedMSM:
         _, first = eng.column_moments_partial(x)
         check_d2d = first.to_host()
         b["shift"].copy_from_host(check_d2d)
-        if comm and comm.world > 1:
+        if comm and (comm.world > 1 or self.always_exchange):
             comm.broadcast("shift", 0)
 
     def step(self) -> None:
         from ._lib import check, lib
 
         eng, cfg, b, comm = self.eng, self.cfg, self.buf, self.comm
-        multi = comm is not None and comm.world > 1
+        multi = comm is not None and (comm.world > 1 or self.always_exchange)
         F, d, k = cfg.n_features, cfg.tica_dim, cfg.k
         # 1. standardisation moments
         eng.column_moments_partial(self.x, shift=b["shift"], sums=b["mom_sums"])
