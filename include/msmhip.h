@@ -364,13 +364,33 @@ msm_status msm_embed_full(msm_ctx* ctx, const double* d_T_active, const double* 
  *            descending real part, first dropped, |real part| clipped to [1e-12, 1-1e-12],
  *            t = -max(1, lag)/ln(.), lag = d_lags[b]; NaN padding when fewer exist
  *   d_status int32 [batch]: 0, or the hqr failure index
+ *   freeze_tol > 0 with init == 0: matrices whose d_change (left by the previous call) is already
+ *            <= freeze_tol are skipped and keep all their outputs (uneven batches: lag scans,
+ *            posterior samples); 0 iterates every matrix
  * d_workspace must hold msm_spectrum_workspace_bytes(n_max, p, batch) bytes. */
 size_t msm_spectrum_workspace_bytes(int n_max, int p, int batch);
 msm_status msm_spectrum(msm_ctx* ctx, const double* d_T, int64_t t_stride, int ld, const int32_t* d_n,
                         int n_max, int batch, int p, int n_iter, int init, uint64_t seed, int n_watch,
                         void* d_workspace, double* d_ritz, double* d_pi, int64_t pi_stride,
                         double* d_change, int32_t* d_status, int n_its, const double* d_lags,
-                        double* d_its_eig, double* d_its_ts);
+                        double* d_its_eig, double* d_its_ts, double freeze_tol);
+
+/* Posterior samples of a mode-1 estimate for the implied-timescale confidence intervals
+ * (ITSMixin._its_compute_for_single_lag, S/markov_state_model/_its.py:272-357, which asks
+ * deeptime's BayesianMSM for n_samples matrices; that sampler's stream is not reproducible, so
+ * this draws from the closed-form posterior of the estimator msm_transition_matrix implements):
+ * row i of every sample ~ Dirichlet(C[active[i], active[:]] + alpha), rows independent.
+ * d_counts / d_active / d_n_active as for msm_transition_matrix mode 1.  Sample s (numbered
+ * first_sample + s) is written packed (n_active x n_active, row stride ld) at d_T + s*t_stride:
+ * the layout msm_spectrum's batch takes.  Variates are Philox4x32-10 keyed by `seed` with counter
+ * (column, row, sample number, attempt): a cell does not depend on the batch it is drawn in. */
+msm_status msm_sample_transition_matrices(msm_ctx* ctx, const void* d_counts, int counts_are_f64, int k,
+                                          const int32_t* d_active, const int32_t* d_n_active, double alpha,
+                                          uint64_t seed, int first_sample, int n_samples, double* d_T,
+                                          int64_t t_stride, int ld);
+
+/* One Philox4x32-10 block (known-answer test of the generator): d_out uint32 [4]. */
+msm_status msm_philox4x32(msm_ctx* ctx, uint64_t key, const uint32_t counter[4], uint32_t* d_out);
 
 /* ---- Chapman-Kolmogorov test ---------------------------------------------
  * msm_gemm_f64: C (m x n) = A (m x k) . B (k x n), row-major fp64 on the matrix cores; every

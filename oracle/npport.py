@@ -763,3 +763,80 @@ class GridStates:
     def centers(self):
         mesh = np.meshgrid(*[(e[:-1] + e[1:]) / 2.0 for e in self.edges], indexing="ij")
         return np.stack([m.ravel() for m in mesh], axis=1)
+
+
+# ---- posterior transition-matrix samples (engine definition: pmarlo_amd/csrc/posterior.hip) ------
+def philox4x32(key, counter):
+    """Philox4x32-10 (Salmon, Moraes, Dror, Shaw, SC'11) on arrays: counter uint32 [..., 4] -> [..., 4]."""
+    c = np.array(counter, dtype=np.uint64, copy=True)
+    k0 = np.uint64(int(key) & 0xFFFFFFFF)
+    k1 = np.uint64((int(key) >> 32) & 0xFFFFFFFF)
+    m32 = np.uint64(0xFFFFFFFF)
+    for _ in range(10):
+        p0 = np.uint64(0xD2511F53) * c[..., 0]
+        p1 = np.uint64(0xCD9E8D57) * c[..., 2]
+        n0 = (p1 >> np.uint64(32)) ^ c[..., 1] ^ k0
+        n2 = (p0 >> np.uint64(32)) ^ c[..., 3] ^ k1
+        c = np.stack([n0, p1 & m32, n2, p0 & m32], axis=-1)
+        k0 = (k0 + np.uint64(0x9E3779B9)) & m32
+        k1 = (k1 + np.uint64(0xBB67AE85)) & m32
+    return c.astype(np.uint32)
+
+
+def _unit_open(hi, lo):
+    v = ((hi.astype(np.uint64) << np.uint64(32)) | lo.astype(np.uint64)) >> np.uint64(11)
+    return (v.astype(np.float64) + 0.5) * 2.0 ** -53
+
+
+def sample_transition_matrices(C_active_plus_alpha, seed, first_sample, n_samples):
+    """Rows ~ Dirichlet(shape row) from Marsaglia-Tsang gamma variates carried as logarithms, random
+    numbers keyed as in the device kernel: counter (column, row, sample, 2*attempt [+1])."""
+    A = np.asarray(C_active_plus_alpha, dtype=np.float64)
+    n = A.shape[0]
+    out = np.empty((n_samples, n, n))
+    col, row = np.meshgrid(np.arange(n, dtype=np.uint64), np.arange(n, dtype=np.uint64))
+    boost = A < 1.0
+    a = np.where(boost, A + 1.0, A)
+    d = a - 1.0 / 3.0
+    c = 1.0 / np.sqrt(9.0 * d)
+    for s in range(n_samples):
+        lg = np.full((n, n), np.nan)
+        todo = A > 0
+        attempt = 0
+        while todo.any():
+            ctr = np.stack([col, row, np.full_like(col, first_sample + s), np.full_like(col, 2 * attempt)], axis=-1)
+            r = philox4x32(seed, ctr)
+            ctr[..., 3] += np.uint64(1)
+            q = philox4x32(seed, ctr)
+            u1, u2 = _unit_open(r[..., 0], r[..., 1]), _unit_open(r[..., 2], r[..., 3])
+            u3, u4 = _unit_open(q[..., 0], q[..., 1]), _unit_open(q[..., 2], q[..., 3])
+            attempt += 1
+            x = np.sqrt(-2.0 * np.log(u1)) * np.cos(2.0 * np.pi * u2)
+            t = 1.0 + c * x
+            with np.errstate(invalid="ignore", divide="ignore"):
+                v = t * t * t
+                lv = np.log(v)
+                ok = (t > 0) & ((u3 < 1.0 - 0.0331 * x ** 4) | (np.log(u3) < 0.5 * x * x + d * (1.0 - v + lv))
+                                | (attempt >= 64))
+                val = np.log(d) + lv + np.where(boost, np.log(u4) / np.where(boost, A, 1.0), 0.0)
+            take = todo & ok
+            lg[take] = val[take]
+            todo &= ~ok
+        lg[~(A > 0)] = -np.inf
+        mx = lg.max(axis=1, keepdims=True)
+        e = np.exp(lg - mx)
+        out[s] = e / e.sum(axis=1, keepdims=True)
+    return out
+
+
+def its_posterior_summary(T_samples, lag, n_timescales, q_low, q_high):
+    """_summarize_its_stats (S/markov_state_model/_its.py:543-625) over a stack of sampled matrices."""
+    ev = np.stack([its_from_transition_matrix(T, lag, n_timescales)[0] for T in T_samples])
+    ts = np.stack([its_from_transition_matrix(T, lag, n_timescales)[1] for T in T_samples])
+    with np.errstate(divide="ignore", invalid="ignore"):
+        rate = np.where(np.isfinite(ts), 1.0 / ts, np.nan)
+    stats = {}
+    for name, arr in (("eigenvalues", ev), ("timescales", ts), ("rates", rate)):
+        stats[name] = np.nanmedian(arr, axis=0)
+        stats[name + "_ci"] = np.stack([np.nanpercentile(arr, q_low, axis=0), np.nanpercentile(arr, q_high, axis=0)], -1)
+    return stats

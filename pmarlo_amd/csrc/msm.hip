@@ -153,6 +153,7 @@ struct SpecArgs {
     size_t pi_stride;
     double* change;       // [batch] max relative change of the top `n_watch` Ritz values over the last check gap
     int n_watch;
+    double freeze_tol;    // > 0: a matrix whose `change` (from the previous call) is <= this is left as it is
     int check_gap;
     int* status;          // [batch] 0 ok, else hqr failure index
     // implied timescales (optional)
@@ -161,6 +162,14 @@ struct SpecArgs {
     double* its_eig;      // [batch][n_its]
     double* its_ts;       // [batch][n_its]
 };
+
+// Batches converge unevenly (a lag scan, posterior samples): once a matrix has met the caller's
+// tolerance, later calls skip it.  `change` is only written by the last kernel of a call, so every
+// kernel of the next call reads the same value; a (re)start ignores it.
+__device__ __forceinline__ bool spec_frozen(const SpecArgs& ar, int b) {
+    return ar.freeze_tol > 0.0 && !ar.init && ar.change[b] <= ar.freeze_tol;
+}
+
 
 struct SpecShared {
     double G[kMaxP * kMaxP];
@@ -261,7 +270,7 @@ __global__ __launch_bounds__(kApplyThreads) void spec_apply_kernel(SpecArgs ar, 
                                                                   double* __restrict__ partial_all, size_t part_stride) {
     const int b = blockIdx.z;
     const int n = ar.n_ptr ? ar.n_ptr[b] : ar.n_fixed;
-    if (n <= 0) return;
+    if (n <= 0 || spec_frozen(ar, b)) return;
     const int p = min(ar.p, n);
     const double* T = ar.T + (size_t)b * ar.t_stride;
     const double* Z = Zin_all + (size_t)b * ar.zw_stride;
@@ -399,6 +408,7 @@ __global__ __launch_bounds__(kSolveThreads) void spec_step_kernel(SpecArgs ar, i
     // matrix, the triangular solve and the residuals.
     double* W = lds_w ? w_lds : Wg;
     double* ritz = ar.ritz + (size_t)b * 4 * kMaxP;
+    if (spec_frozen(ar, b)) return;   // uniform over the workgroup; outputs of the previous call stand
     if (tid == 0) sh.status = 0;
     __syncthreads();
     if (n <= 0) {
@@ -632,7 +642,7 @@ size_t msm_spectrum_workspace_bytes(int n_max, int p, int batch) {
 msm_status msm_spectrum(msm_ctx* ctx, const double* d_T, int64_t t_stride, int ld, const int32_t* d_n, int n_max,
                         int batch, int p, int n_iter, int init, uint64_t seed, int n_watch, void* d_workspace,
                         double* d_ritz, double* d_pi, int64_t pi_stride, double* d_change, int32_t* d_status,
-                        int n_its, const double* d_lags, double* d_its_eig, double* d_its_ts) {
+                        int n_its, const double* d_lags, double* d_its_eig, double* d_its_ts, double freeze_tol) {
     if (!ctx) return MSM_ERR_INVALID;
     MSM_REQUIRE(ctx, n_max >= 1 && batch >= 1 && ld >= n_max, "msm_spectrum: bad shape");
     MSM_REQUIRE(ctx, p >= 1 && p <= kMaxP, "msm_spectrum: need 1 <= p <= %d", kMaxP);
@@ -651,6 +661,7 @@ msm_status msm_spectrum(msm_ctx* ctx, const double* d_T, int64_t t_stride, int l
     ar.zw_stride = zw;
     ar.ritz = d_ritz; ar.pi = d_pi; ar.pi_stride = (size_t)pi_stride; ar.change = d_change;
     ar.n_watch = n_watch;
+    ar.freeze_tol = freeze_tol;
     ar.status = d_status; ar.n_its = n_its; ar.lags = d_lags; ar.its_eig = d_its_eig; ar.its_ts = d_its_ts;
     // orthogonalise every kOrthoEvery applications and always after the last one; compare the
     // complex Ritz values against those right after an earlier orthogonalisation.  Every step:
@@ -681,7 +692,8 @@ msm_status msm_spectrum(msm_ctx* ctx, const double* d_T, int64_t t_stride, int l
             hipLaunchKernelGGL(spec_step_kernel<false>, dim3(batch), dim3(kSolveThreads), 0, ctx->stream, ar, mode, z,
                                w, partial, part_stride);
     };
-    MSM_HIP(ctx, hipMemsetAsync(d_status, 0, sizeof(int32_t) * batch, ctx->stream));
+    if (init || !(freeze_tol > 0.0))   // frozen matrices keep their status
+        MSM_HIP(ctx, hipMemsetAsync(d_status, 0, sizeof(int32_t) * batch, ctx->stream));
     if (init) step(kStepInit, bufA, bufB);
     MSM_CHECK_LAUNCH(ctx);
     // invariant at the top of an iteration: the current basis is in `cur`

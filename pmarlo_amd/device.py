@@ -672,25 +672,30 @@ class Engine:
         launches = 0
         restart = True
         since_restart = 0
-        worst = float("inf")
+        worst = prev = float("inf")
         for launch in range(max_launches):
             check(lib.msm_spectrum(self.handle, T.ptr, k * k, k, n.ptr if n is not None else None, k, B, p,
                                    int(n_iter), int(restart), int(seed), max(n_its + 1, 1), ws.ptr, ritz.ptr,
                                    pi.ptr if pi is not None else None, k, change.ptr, status.ptr, int(n_its),
-                                   lag_d.ptr, its_eig.ptr, its_ts.ptr), self.handle)
+                                   lag_d.ptr, its_eig.ptr, its_ts.ptr, float(tol) if B > 1 else 0.0), self.handle)
             launches += 1
             restart = False
             since_restart += 1
-            worst = float(np.max(change.to_host()))
+            prev, worst = worst, float(np.max(change.to_host()))
             if worst <= tol:
                 break
             # slow convergence = the watched eigenvalues are close to lambda_{p+1}: a wider basis moves
-            # that ratio down at little cost per iteration (restart with twice the subspace, up to 32)
-            if since_restart >= 8 and p < min(32, k):
-                p = int(min(32, k, 2 * p))
-                ws = self.empty((int(lib.msm_spectrum_workspace_bytes(k, p, B)),), np.uint8)
-                self._spec_cache = (key, ws, ritz, change, status, its_eig, its_ts)
-                restart, since_restart = True, 0
+            # that ratio down at little cost per iteration.  The decay of the worst residual between two
+            # launches predicts how many more this basis needs; more than a handful -> restart with the
+            # widest subspace right away (converged matrices of a batch are frozen, not re-iterated)
+            if since_restart >= 2 and p < min(32, k):
+                rate = worst / prev if 0.0 < prev < float("inf") else 1.0
+                remaining = np.log(tol / worst) / np.log(rate) if 0.0 < rate < 1.0 else float("inf")
+                if remaining > 6:
+                    p = int(min(32, k))
+                    ws = self.empty((int(lib.msm_spectrum_workspace_bytes(k, p, B)),), np.uint8)
+                    self._spec_cache = (key, ws, ritz, change, status, its_eig, its_ts)
+                    restart, since_restart, worst = True, 0, float("inf")
         else:
             if not allow_unconverged:
                 raise _lib.MsmError(
@@ -706,6 +711,32 @@ class Engine:
             out["its_eig"] = its_eig.to_host()
             out["its_ts"] = its_ts.to_host()
         return out
+
+
+    def sample_transition_matrices(self, counts: DeviceArray, active: DeviceArray, n_active: DeviceArray, *,
+                                   alpha: float, seed: int, n_samples: int, first_sample: int = 0,
+                                   out: DeviceArray | None = None) -> DeviceArray:
+        """n_samples posterior draws [n_samples, k, k] (packed active blocks) of a mode-1 estimate."""
+        k = counts.shape[-1]
+        if out is None:
+            out = self.empty((int(n_samples), k, k), np.float64)
+        done = 0
+        while done < n_samples:                       # grid.y limit: 65535 samples per launch
+            m = min(65535, n_samples - done)
+            check(lib.msm_sample_transition_matrices(
+                self.handle, counts.ptr, int(counts.dtype == np.float64), k, active.ptr, n_active.ptr, float(alpha),
+                int(seed) & (2 ** 64 - 1), int(first_sample + done), m, out.ptr + done * k * k * 8, k * k, k),
+                self.handle)
+            done += m
+        return out
+
+    def philox4x32(self, key: int, counter) -> np.ndarray:
+        import ctypes
+
+        out = self.empty((4,), np.uint32)
+        c = (ctypes.c_uint32 * 4)(*[int(v) & 0xFFFFFFFF for v in counter])
+        check(lib.msm_philox4x32(self.handle, int(key) & (2 ** 64 - 1), c, out.ptr), self.handle)
+        return out.to_host()
 
 
 _ENGINES: dict[int, Engine] = {}

@@ -4,7 +4,14 @@ from .clustering import ClusteringResult, cluster_microstates  # noqa: F401
 from .estimation import (build_msm, compute_free_energies, count_transitions,  # noqa: F401
                          ensure_connected_counts, finalize_transition_and_stationary)
 from .features import MSMFeatures, ca_distance_pairs, compute_msm_features  # noqa: F401
-from .its import compute_implied_timescales, safe_timescales  # noqa: F401
+from .its import (  # noqa: F401
+    DEFAULT_ITS_LAGS,
+    candidate_lag_ladder,
+    compute_implied_timescales,
+    detect_timescale_plateau,
+    safe_timescales,
+    select_lag_from_its,
+)
 from .reduction import pca_reduce, reduce_features, tica_reduce  # noqa: F401
 from .tpt import (ReactiveFlux, compute_committor, compute_macro_mfpt, compute_macro_populations,  # noqa: F401
                   lump_micro_to_macro_T, reactive_flux)

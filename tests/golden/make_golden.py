@@ -377,7 +377,38 @@ def golden_grid():
     np.savez_compressed(OUT / "grid.npz", **out)
 
 
+def golden_its_helpers():
+    """ITSMixin._detect_timescale_plateau, _its_alpha_tail_bounds and _its_default_lag_times
+    (markov_state_model/_its.py; the module imports without deeptime, these methods never reach it)."""
+    from pmarlo.markov_state_model._its import ITSMixin
+
+    host = ITSMixin.__new__(ITSMixin)
+    rng = np.random.default_rng(3)
+    out = {"default_lags": np.asarray(host._its_default_lag_times(None)),
+           "tails": np.asarray([host._its_alpha_tail_bounds(c) for c in (0.95, 0.9, 0.5)])}
+    lags = np.asarray([1, 2, 3, 5, 8, 10, 15, 20, 30, 40, 50, 75], dtype=float)
+    series = []
+    for case in range(12):
+        ts = 40.0 * (1.0 - np.exp(-lags / rng.uniform(1.0, 12.0))) + rng.normal(scale=rng.uniform(0.0, 1.5), size=lags.size)
+        if case % 4 == 1:
+            ts[rng.integers(0, lags.size)] = np.nan
+        if case % 4 == 2:
+            ts[:3] = -1.0
+        if case == 11:
+            ts[:] = np.nan
+        series.append(np.stack([ts, 0.3 * ts], axis=1))
+    series = np.asarray(series)
+    wins = []
+    for ts in series:
+        for m, eps in ((2, 0.05), (3, 0.1), (4, 0.2), (1, 0.0)):
+            w = host._detect_timescale_plateau(lags, ts, m, eps)
+            wins.append((np.nan, np.nan) if w is None else w)
+    out.update(plateau_lags=lags, plateau_series=series, plateau_windows=np.asarray(wins, dtype=float))
+    np.savez_compressed(OUT / "its_helpers.npz", **out)
+
+
 if __name__ == "__main__":
+    golden_its_helpers()
     golden_grid()
     golden_pca()
     golden_fes()
