@@ -46,7 +46,7 @@ def segments_to_bounds(
 class DeviceArray:
     """A shaped, typed block of device memory."""
 
-    __slots__ = ("engine", "ptr", "shape", "dtype", "_owned")
+    __slots__ = ("engine", "ptr", "shape", "dtype", "_owned", "_base")
 
     def __init__(self, engine: "Engine", ptr: int, shape, dtype, owned: bool):
         self.engine = engine
@@ -54,6 +54,7 @@ class DeviceArray:
         self.shape = tuple(int(s) for s in (shape if isinstance(shape, (tuple, list)) else (shape,)))
         self.dtype = np.dtype(dtype)
         self._owned = owned
+        self._base = None
 
     @property
     def size(self) -> int:
@@ -93,7 +94,9 @@ class DeviceArray:
 
     def view(self, shape, dtype=None, offset_elems: int = 0) -> "DeviceArray":
         dtype = self.dtype if dtype is None else np.dtype(dtype)
-        return DeviceArray(self.engine, self.ptr + offset_elems * self.dtype.itemsize, shape, dtype, False)
+        v = DeviceArray(self.engine, self.ptr + offset_elems * self.dtype.itemsize, shape, dtype, False)
+        v._base = self      # a view keeps the allocation it points into alive
+        return v
 
     def free(self) -> None:
         if self._owned and self.ptr and self.engine.handle:
