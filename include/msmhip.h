@@ -375,6 +375,18 @@ msm_status msm_spectrum(msm_ctx* ctx, const double* d_T, int64_t t_stride, int l
                         double* d_change, int32_t* d_status, int n_its, const double* d_lags,
                         double* d_its_eig, double* d_its_ts, double freeze_tol);
 
+/* Reversible maximum-likelihood estimate: deeptime's MaximumLikelihoodMSM(reversible=True) as
+ * called by _fit_msm_deeptime (S/markov_state_model/_msm_utils.py:210-262) and the lag selector
+ * (S/markov_state_model/ck_its_selector.py:395-401), restated from the published fixed-point
+ * iteration x_ij <- (c_ij + c_ji) / (c_i/x_i + c_j/x_j) on the row sums x_i, normalised every step,
+ * until max_i |x_i - x_i'| / ((x_i + x_i')/2) <= maxerr (deeptime: 1e-8) or maxiter (1e6).
+ * d_counts f64 [n, ld] must be a connected count matrix (e.g. ensure_connected_counts' result);
+ * d_T f64 [n, ldt] row-stochastic with pi_i T_ij = pi_j T_ji, d_pi f64 [n] (may be NULL).
+ * The convergence test polls the host (every 32, 64, ... 1024 iterations): the call synchronises the
+ * stream and cannot be captured.  *h_iterations / *h_err (host, may be NULL) report what was run. */
+msm_status msm_reversible_mle(msm_ctx* ctx, const double* d_counts, int n, int ld, double maxerr, int maxiter,
+                              double* d_T, int ldt, double* d_pi, int* h_iterations, double* h_err);
+
 /* Posterior samples of a mode-1 estimate for the implied-timescale confidence intervals
  * (ITSMixin._its_compute_for_single_lag, S/markov_state_model/_its.py:272-357, which asks
  * deeptime's BayesianMSM for n_samples matrices; that sampler's stream is not reproducible, so

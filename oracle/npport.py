@@ -840,3 +840,33 @@ def its_posterior_summary(T_samples, lag, n_timescales, q_low, q_high):
         stats[name] = np.nanmedian(arr, axis=0)
         stats[name + "_ci"] = np.stack([np.nanpercentile(arr, q_low, axis=0), np.nanpercentile(arr, q_high, axis=0)], -1)
     return stats
+
+
+# ---- reversible maximum-likelihood estimate (engine: pmarlo_amd/csrc/revmle.hip) -----------------
+def reversible_mle(C, maxerr=1e-8, maxiter=1_000_000):
+    """Fixed point x_ij = (c_ij + c_ji) / (c_i/x_i + c_j/x_j) iterated on the row sums (Prinz et al. 2011;
+    deeptime's dense reversible estimator as called at S/markov_state_model/_msm_utils.py:250-256).
+    Returns (T, pi, iterations)."""
+    C = np.asarray(C, dtype=np.float64)
+    c = C.sum(axis=1)
+    C2 = C + C.T
+    x = C2.sum(axis=1)
+    x = x / x.sum()
+    it = 0
+    err = np.inf
+    while it < maxiter and err > maxerr:
+        with np.errstate(divide="ignore", invalid="ignore"):
+            v = np.where(x > 0, c / x, 0.0)
+            den = v[:, None] + v[None, :]
+            f = np.where((C2 > 0) & (den > 0), C2 / den, 0.0)
+        xn = f.sum(axis=1)
+        xn = xn / xn.sum()
+        mid = 0.5 * (x + xn)
+        err = np.max(np.where(mid > 0, np.abs(x - xn) / np.where(mid > 0, mid, 1.0), 0.0))
+        x = xn
+        it += 1
+    v = np.where(x > 0, c / x, 0.0)
+    den = v[:, None] + v[None, :]
+    with np.errstate(divide="ignore", invalid="ignore"):
+        f = np.where((C2 > 0) & (den > 0), C2 / den, 0.0)
+    return f / f.sum(axis=1, keepdims=True), x, it

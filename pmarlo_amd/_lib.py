@@ -83,6 +83,7 @@ _PROTOTYPES: dict[str, tuple] = {
                             _i64, _vp, _vp, _i32, _vp, _vp, _vp, _f64]),
     "msm_sample_transition_matrices": (_i32, [_vp, _vp, _i32, _i32, _vp, _vp, _f64, C.c_uint64, _i32, _i32, _vp, _i64,
                                               _i32]),
+    "msm_reversible_mle": (_i32, [_vp, _vp, _i32, _i32, _f64, _i32, _vp, _i32, _vp, _vp, _vp]),
     "msm_philox4x32": (_i32, [_vp, C.c_uint64, _vp, _vp]),
     "msm_gemm_f64": (_i32, [_vp, _i32, _i32, _i32, _vp, _i64, _vp, _i64, _vp, _i64]),
     "msm_weighted_stats": (_i32, [_vp, _vp, _i64, _i64, _vp, _vp]),

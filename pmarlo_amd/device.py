@@ -733,6 +733,17 @@ class Engine:
             done += m
         return out
 
+    def reversible_mle(self, counts: DeviceArray, *, maxerr: float = 1e-8, maxiter: int = 1_000_000) -> dict:
+        """Reversible maximum-likelihood T and pi of a connected f64 count matrix [n, n]."""
+        import ctypes
+
+        n = counts.shape[0]
+        T, pi = self.empty((n, n), np.float64), self.empty((n,), np.float64)
+        it, err = ctypes.c_int(0), ctypes.c_double(0.0)
+        check(lib.msm_reversible_mle(self.handle, counts.ptr, n, counts.shape[1], float(maxerr), int(maxiter), T.ptr, n,
+                                     pi.ptr, ctypes.byref(it), ctypes.byref(err)), self.handle)
+        return {"T": T, "pi": pi, "iterations": it.value, "err": err.value}
+
     def philox4x32(self, key: int, counter) -> np.ndarray:
         import ctypes
 

@@ -101,3 +101,42 @@ def build_msm(dtrajs: Sequence[np.ndarray], n_states: int, lag_time: int = 20, c
     est = finalize_transition_and_stationary(count_transitions(dtrajs, n_states, lag=lag, count_mode=count_mode))
     est.free_energies = compute_free_energies(est.stationary_distribution, temperature)
     return est
+
+
+def fit_reversible_msm(counts: np.ndarray, *, maxerr: float = 1e-8, maxiter: int = 1_000_000):
+    """ensure_connected_counts + MaximumLikelihoodMSM(reversible=True) + _expand_results
+    (_fit_msm_deeptime / _expand_results, S/markov_state_model/_msm_utils.py:210-281): T = I and
+    pi = 0 outside the active block.  The fixed-point iteration runs on the device."""
+    C = np.asarray(counts, dtype=np.float64)
+    n = C.shape[0]
+    res = ensure_connected_counts(C)
+    T_full, pi_full = np.eye(n), np.zeros(n)
+    if res.counts.size == 0:
+        return T_full, pi_full, res.active
+    eng = get_engine()
+    out = eng.reversible_mle(eng.to_device(np.ascontiguousarray(res.counts)), maxerr=maxerr, maxiter=maxiter)
+    T_full[np.ix_(res.active, res.active)] = out["T"].to_host()
+    pi_full[res.active] = out["pi"].to_host()
+    return T_full, pi_full, res.active
+
+
+def build_simple_msm(dtrajs: Sequence[np.ndarray], n_states: int | None = None, lag: int = 20,
+                     count_mode: str = "sliding") -> tuple[np.ndarray, np.ndarray]:
+    """(transition_matrix, stationary_distribution) of the reversible estimate
+    (build_simple_msm, S/markov_state_model/_msm_utils.py:163-187)."""
+    if not dtrajs:
+        return np.empty((0, 0), dtype=float), np.empty((0,), dtype=float)
+    if n_states is None:                                 # _infer_n_states :190-207: negative labels = unassigned
+        top = max((int(np.max(d)) for d in dtrajs if len(d)), default=-1)
+        n_states = top + 1 if top >= 0 else 0
+    n_states = int(n_states)
+    if n_states == 0:
+        return np.empty((0, 0), dtype=float), np.empty((0,), dtype=float)
+    C = count_transitions(dtrajs, n_states, lag=int(max(1, lag)), count_mode=count_mode)
+    T, pi, _ = fit_reversible_msm(C)
+    # check_transition_matrix (S/utils/msm_utils.py): rows sum to one, pi is stationary
+    if not np.allclose(T.sum(axis=1), 1.0, atol=1e-12):
+        raise ValueError("transition matrix rows must sum to 1")
+    if pi.sum() > 0 and not np.allclose(pi @ T, pi, atol=1e-8):
+        raise ValueError("stationary distribution is not invariant under T")
+    return T, pi
