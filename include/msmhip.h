@@ -367,13 +367,17 @@ msm_status msm_embed_full(msm_ctx* ctx, const double* d_T_active, const double* 
  *   freeze_tol > 0 with init == 0: matrices whose d_change (left by the previous call) is already
  *            <= freeze_tol are skipped and keep all their outputs (uneven batches: lag scans,
  *            posterior samples); 0 iterates every matrix
+ *   d_vecs   f64 [batch][n_vecs][n_max] or NULL: left eigenvectors (x'T = theta x') of the Ritz values
+ *            in descending magnitude, unit 2-norm, largest-magnitude component positive; NaN rows for
+ *            complex pairs.
+ *            For a reversible T the right eigenvectors are x / pi (PCCA+ input)
  * d_workspace must hold msm_spectrum_workspace_bytes(n_max, p, batch) bytes. */
 size_t msm_spectrum_workspace_bytes(int n_max, int p, int batch);
 msm_status msm_spectrum(msm_ctx* ctx, const double* d_T, int64_t t_stride, int ld, const int32_t* d_n,
                         int n_max, int batch, int p, int n_iter, int init, uint64_t seed, int n_watch,
                         void* d_workspace, double* d_ritz, double* d_pi, int64_t pi_stride,
                         double* d_change, int32_t* d_status, int n_its, const double* d_lags,
-                        double* d_its_eig, double* d_its_ts, double freeze_tol);
+                        double* d_its_eig, double* d_its_ts, double freeze_tol, double* d_vecs, int n_vecs);
 
 /* Reversible maximum-likelihood estimate: deeptime's MaximumLikelihoodMSM(reversible=True) as
  * called by _fit_msm_deeptime (S/markov_state_model/_msm_utils.py:210-262) and the lag selector

@@ -870,3 +870,52 @@ def reversible_mle(C, maxerr=1e-8, maxiter=1_000_000):
     with np.errstate(divide="ignore", invalid="ignore"):
         f = np.where((C2 > 0) & (den > 0), C2 / den, 0.0)
     return f / f.sum(axis=1, keepdims=True), x, it
+
+
+# ---- PCCA+ (deeptime.markov.pcca as used at S/markov_state_model/_msm_utils.py:284-299) -----------
+def pcca_memberships(T, m):
+    """Inner simplex start + Roeblitz-Weber crispness optimisation on the m dominant right eigenvectors of a
+    reversible T (eigenvectors through the pi-symmetrised matrix, ordered by |eigenvalue|)."""
+    from scipy.optimize import fmin
+
+    T = np.asarray(T, dtype=np.float64)
+    pi = stationary_distribution(T)
+    if not np.allclose(pi[:, None] * T, (pi[:, None] * T).T, rtol=1e-5, atol=1e-15):
+        raise ValueError("Transition matrix does not fulfill detailed balance")
+    sq = np.sqrt(pi)
+    w, U = np.linalg.eigh(sq[:, None] * T / sq[None, :])
+    order = np.argsort(-np.abs(w))[:m]
+    R = U[:, order] / sq[:, None]
+    for q in range(m):
+        R[:, q] /= np.sqrt(np.sum(pi * R[:, q] ** 2))
+    R[:, 0] = np.abs(R[:, 0])
+    # inner simplex algorithm, row by row
+    rows = R.copy()
+    picked = [max(range(R.shape[0]), key=lambda i: float(np.linalg.norm(rows[i])))]
+    rows = rows - R[picked[0]]
+    for _ in range(1, m):
+        base = rows[picked[-1]].copy()
+        if np.linalg.norm(base) > 0:
+            base = base / np.linalg.norm(base)
+        best, far = -1, -1.0
+        for i in range(rows.shape[0]):
+            rows[i] = rows[i] - (base @ rows[i]) * base
+            d = float(np.linalg.norm(rows[i]))
+            if d > far and i not in picked:
+                best, far = i, d
+        picked.append(best)
+    A0 = np.linalg.inv(R[picked])
+
+    def fill(block):
+        body = np.hstack([-block.sum(axis=1)[:, None], block])
+        top = (-(R[:, 1:] @ body)).max(axis=0)
+        A = np.vstack([top[None, :], body])
+        return A / top.sum()
+
+    def target(vec):
+        A = fill(vec.reshape(m - 1, m - 1))
+        return -sum(A[j, i] ** 2 / A[0, i] for i in range(m) for j in range(m))
+
+    A = fill(fmin(target, A0[1:, 1:].ravel(), disp=False).reshape(m - 1, m - 1)) if m > 1 else A0
+    chi = np.clip(R @ A, 0.0, 1.0)
+    return chi / chi.sum(axis=1, keepdims=True)

@@ -161,6 +161,9 @@ struct SpecArgs {
     const double* lags;   // [batch]
     double* its_eig;      // [batch][n_its]
     double* its_ts;       // [batch][n_its]
+    // leading left Ritz vectors (optional)
+    double* vecs;         // [batch][n_vecs][n_fixed]
+    int n_vecs;
 };
 
 // Batches converge unevenly (a lag scan, posterior samples): once a matrix has met the caller's
@@ -191,6 +194,20 @@ __device__ double spec_block_sum(double v, SpecShared* sh) {
     if (threadIdx.x == 0) {
         double t = 0.0;
         for (int i = 0; i < (int)(blockDim.x >> 6); ++i) t += sh->red[i];
+        sh->bc = t;
+    }
+    __syncthreads();
+    return sh->bc;
+}
+
+__device__ double spec_block_max(double v, SpecShared* sh) {
+    for (int off = 32; off > 0; off >>= 1) v = fmax(v, __shfl_down(v, off, 64));
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) sh->red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t = -INFINITY;
+        for (int i = 0; i < (int)(blockDim.x >> 6); ++i) t = fmax(t, sh->red[i]);
         sh->bc = t;
     }
     __syncthreads();
@@ -554,6 +571,53 @@ __global__ __launch_bounds__(kSolveThreads) void spec_step_kernel(SpecArgs ar, i
         const double tot = spec_block_sum(part, &sh);
         for (int i = tid; i < n; i += blockDim.x) pi[i] = pi[i] / tot;
     }
+    // leading left eigenvectors (x' T = theta x'), Ritz values by descending magnitude (the order
+    // deeptime's eigenvectors() returns); unit 2-norm, the component of largest magnitude (lowest
+    // index on ties) positive; NaN for a complex pair or beyond the subspace
+    if (ar.vecs && ar.n_vecs > 0) {
+        if (tid == 0) {
+            for (int i = 0; i < p; ++i) {
+                const double mi = sh.wr[i] * sh.wr[i] + sh.wi[i] * sh.wi[i];
+                int rank = 0;
+                for (int j = 0; j < p; ++j) {
+                    const double mj = sh.wr[j] * sh.wr[j] + sh.wi[j] * sh.wi[j];
+                    rank += (mj > mi) || (mj == mi && j < i);
+                }
+                sh.order[rank] = i;
+            }
+        }
+        __syncthreads();
+        for (int q = 0; q < ar.n_vecs; ++q) {
+            double* out = ar.vecs + ((size_t)b * ar.n_vecs + q) * ar.n_fixed;
+            const int id = q < p ? sh.order[q] : -1;
+            if (id < 0 || sh.wi[id] != 0.0) {
+                for (int i = tid; i < n; i += blockDim.x) out[i] = __builtin_nan("");
+                continue;
+            }
+            __syncthreads();
+            if (tid == 0) small_eig::eigenvector(sh.H, p, p, sh.wr[id], sh.y, sh.Hw);
+            __syncthreads();
+            double nn = 0.0, big = 0.0;
+            for (int i = tid; i < n; i += blockDim.x) {
+                double v = 0.0;
+                for (int c = 0; c < p; ++c) v = fma(Z[(size_t)i * p + c], sh.y[c], v);
+                out[i] = v;
+                nn = fma(v, v, nn);
+                big = fmax(big, fabs(v));
+            }
+            nn = spec_block_sum(nn, &sh);
+            big = spec_block_max(big, &sh);
+            double first = -(double)n;                       // -(lowest index that attains the maximum)
+            for (int i = tid; i < n; i += blockDim.x)
+                if (fabs(out[i]) == big) { first = -(double)i; break; }
+            first = spec_block_max(first, &sh);
+            const int lead = min(n - 1, max(0, (int)(-first)));
+            const double scale = (out[lead] < 0.0 ? -1.0 : 1.0) / sqrt(fmax(nn, 1e-300));
+            __syncthreads();                                 // every thread has read out[lead]
+            for (int i = tid; i < n; i += blockDim.x) out[i] *= scale;
+        }
+        __syncthreads();
+    }
     // implied timescales (_its.py:543-604 on one matrix; utils.py:17-57)
     if (ar.n_its > 0 && tid == 0) {
         const int n_its = ar.n_its;
@@ -642,8 +706,10 @@ size_t msm_spectrum_workspace_bytes(int n_max, int p, int batch) {
 msm_status msm_spectrum(msm_ctx* ctx, const double* d_T, int64_t t_stride, int ld, const int32_t* d_n, int n_max,
                         int batch, int p, int n_iter, int init, uint64_t seed, int n_watch, void* d_workspace,
                         double* d_ritz, double* d_pi, int64_t pi_stride, double* d_change, int32_t* d_status,
-                        int n_its, const double* d_lags, double* d_its_eig, double* d_its_ts, double freeze_tol) {
+                        int n_its, const double* d_lags, double* d_its_eig, double* d_its_ts, double freeze_tol,
+                        double* d_vecs, int n_vecs) {
     if (!ctx) return MSM_ERR_INVALID;
+    MSM_REQUIRE(ctx, n_vecs >= 0 && (n_vecs == 0 || d_vecs), "msm_spectrum: d_vecs missing");
     MSM_REQUIRE(ctx, n_max >= 1 && batch >= 1 && ld >= n_max, "msm_spectrum: bad shape");
     MSM_REQUIRE(ctx, p >= 1 && p <= kMaxP, "msm_spectrum: need 1 <= p <= %d", kMaxP);
     MSM_REQUIRE(ctx, n_iter >= 0 && n_its >= 0 && n_its < kMaxP, "msm_spectrum: bad n_iter / n_its");
@@ -662,6 +728,7 @@ msm_status msm_spectrum(msm_ctx* ctx, const double* d_T, int64_t t_stride, int l
     ar.ritz = d_ritz; ar.pi = d_pi; ar.pi_stride = (size_t)pi_stride; ar.change = d_change;
     ar.n_watch = n_watch;
     ar.freeze_tol = freeze_tol;
+    ar.vecs = d_vecs; ar.n_vecs = n_vecs;
     ar.status = d_status; ar.n_its = n_its; ar.lags = d_lags; ar.its_eig = d_its_eig; ar.its_ts = d_its_ts;
     // orthogonalise every kOrthoEvery applications and always after the last one; compare the
     // complex Ritz values against those right after an earlier orthogonalisation.  Every step:

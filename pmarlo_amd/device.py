@@ -649,14 +649,17 @@ class Engine:
 
     def spectrum(self, T: DeviceArray, *, n: DeviceArray | None = None, n_its: int = 0, lags=None,
                  p: int | None = None, want_pi: bool = True, tol: float = 1e-9, n_iter: int = 24,
-                 max_launches: int = 100, seed: int = 0, allow_unconverged: bool = False) -> dict:
+                 max_launches: int = 100, seed: int = 0, allow_unconverged: bool = False, n_vecs: int = 0,
+                 n_watch: int | None = None) -> dict:
         """Leading Ritz values / stationary distribution / implied timescales of one matrix
         [k,k] or a batch [B,k,k] of packed row-stochastic matrices (orders in `n`, int32 [B])."""
         batched = len(T.shape) == 3
         B = T.shape[0] if batched else 1
         k = T.shape[-1]
+        n_vecs = int(min(n_vecs, 32, k))
+        watch = int(n_watch) if n_watch is not None else max(n_its + 1, n_vecs, 1)
         if p is None:
-            p = min(32, max(n_its + 1 + 6, 8))
+            p = min(32, max(watch + 6, 8))
         p = int(min(p, 32, k))
         ws_bytes = int(lib.msm_spectrum_workspace_bytes(k, p, B))
         # the solver's buffers are kept between calls of the same shape (a lag scan calls this once
@@ -671,6 +674,7 @@ class Engine:
             self._spec_cache = cache
         _, ws, ritz, change, status, its_eig, its_ts = cache
         pi = self.empty((B, k), np.float64) if want_pi else None
+        vecs = self.empty((B, n_vecs, k), np.float64) if n_vecs else None
         lag_d = self.to_device(np.asarray(lags if lags is not None else np.ones(B), np.float64).reshape(B))
         launches = 0
         restart = True
@@ -678,9 +682,10 @@ class Engine:
         worst = prev = float("inf")
         for launch in range(max_launches):
             check(lib.msm_spectrum(self.handle, T.ptr, k * k, k, n.ptr if n is not None else None, k, B, p,
-                                   int(n_iter), int(restart), int(seed), max(n_its + 1, 1), ws.ptr, ritz.ptr,
+                                   int(n_iter), int(restart), int(seed), watch, ws.ptr, ritz.ptr,
                                    pi.ptr if pi is not None else None, k, change.ptr, status.ptr, int(n_its),
-                                   lag_d.ptr, its_eig.ptr, its_ts.ptr, float(tol) if B > 1 else 0.0), self.handle)
+                                   lag_d.ptr, its_eig.ptr, its_ts.ptr, float(tol) if B > 1 else 0.0,
+                                   vecs.ptr if vecs is not None else None, n_vecs), self.handle)
             launches += 1
             restart = False
             since_restart += 1
@@ -709,7 +714,7 @@ class Engine:
             raise _lib.MsmError(f"msm_spectrum: hqr did not converge (status {st.tolist()})")
         r = ritz.to_host()
         out = {"ritz": r[:, :32] + 1j * r[:, 32:64], "p": p, "launches": launches,
-               "residual": change.to_host(), "pi": pi}
+               "residual": change.to_host(), "pi": pi, "vecs": vecs}
         if n_its:
             out["its_eig"] = its_eig.to_host()
             out["its_ts"] = its_ts.to_host()

@@ -17,7 +17,7 @@ int main() {
     const int iters = 40;
     for (int rep = 0; rep < 2; ++rep) {
         hipMemcpyToSymbol(HIP_SYMBOL(g_spec_stamps), z, sizeof(z));
-        if (msm_spectrum(ctx, dT, (int64_t)n * n, n, nullptr, n, 1, p, iters, 1, 0, 6, ws, ritz, pi, n, chg, st, 5, nullptr, ie, it, 0.0)) { printf("%s\n", msm_last_error(ctx)); return 1; }
+        if (msm_spectrum(ctx, dT, (int64_t)n * n, n, nullptr, n, 1, p, iters, 1, 0, 6, ws, ritz, pi, n, chg, st, 5, nullptr, ie, it, 0.0, nullptr, 0)) { printf("%s\n", msm_last_error(ctx)); return 1; }
         msm_sync(ctx);
     }
     unsigned long long s[8]; hipMemcpyFromSymbol(s, HIP_SYMBOL(g_spec_stamps), sizeof(s));
