@@ -428,6 +428,12 @@ msm_status msm_ck_test(msm_ctx* ctx, const double* d_T1, int64_t ld1, const doub
                        int64_t tk_stride, int64_t ldk, int n, const int32_t* h_factors, int n_factors,
                        const double* d_rowcounts, int64_t rc_stride, double* d_mse, double* d_noise);
 
+/* d_out f64 [3] = { sum |P - Q|, sum |Q|, sum (P - Q)^2 } over the n x m entries (fixed order).
+ * The relative L1 error of the lag selector's CK test is out[0] / out[1]
+ * (_compute_ck_error, S/markov_state_model/ck_its_selector.py:211-226). */
+msm_status msm_diff_norms(msm_ctx* ctx, const double* d_P, int64_t ldp, const double* d_Q, int64_t ldq, int n, int m,
+                          double* d_out);
+
 /* ---- free-energy surfaces (S/analysis/fes.py) -----------------------------
  * msm_weighted_stats: d_out6 = {sum w, sum w^2, weighted mean, weighted variance (around that
  *   mean, / sum w), min, max} of the strided coordinate x[i * stride]; d_w NULL = unit weights

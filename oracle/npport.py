@@ -919,3 +919,100 @@ def pcca_memberships(T, m):
     A = fill(fmin(target, A0[1:, 1:].ravel(), disp=False).reshape(m - 1, m - 1)) if m > 1 else A0
     chi = np.clip(R @ A, 0.0, 1.0)
     return chi / chi.sum(axis=1, keepdims=True)
+
+
+# ---- CK / ITS lag selection (S/markov_state_model/ck_its_selector.py:70-599) ---------------------
+def _pair_counts(dtrajs, n, lag):
+    C = np.zeros((n, n))
+    for tr in dtrajs:
+        tr = np.asarray(tr)
+        if tr.size <= lag:
+            continue
+        a, b = tr[:-lag], tr[lag:]
+        ok = (a >= 0) & (a < n) & (b >= 0) & (b < n)
+        np.add.at(C, (a[ok], b[ok]), 1.0)
+    return C
+
+
+def _rownorm_strict(C):
+    rs = C.sum(axis=1)
+    if rs.min() <= 0:
+        raise ValueError("empty row")
+    return C / rs[:, None]
+
+
+def ck_its_evaluate_lag(dtrajs, lag, horizons, n_states, coverage_threshold=0.98, min_median_count=100,
+                        diag_mass_threshold=0.6):
+    """One candidate lag of select_optimal_lag_ck_its: dict with ck_error, coverage, median, n_macro, passed,
+    diag_mass, timescales (slowest first)."""
+    from scipy.sparse.csgraph import connected_components
+
+    C = _pair_counts(dtrajs, n_states, lag)
+    ncomp, lab = connected_components(((C + C.T) > 0).astype(int), directed=False, return_labels=True)
+    coverage = float(np.bincount(lab).max()) / n_states
+    tot = C.sum(0) + C.sum(1)
+    median = int(np.median(tot[tot > 0])) if np.any(tot > 0) else 0
+    out = dict(lag=lag, coverage=coverage, median=median, n_macro=0, ck_error=np.inf, passed=False, diag_mass=np.nan,
+               timescales=None)
+    if coverage < coverage_threshold or median < min_median_count:
+        return out
+    try:
+        T = _rownorm_strict(C)
+        pi = stationary_distribution(T)
+        ev = np.sort(np.real(np.linalg.eigvals(T)))[::-1]
+        n_cand, width = 2, 0.0
+        for m in range(2, min(7, ev.size)):
+            if ev[m - 1] - ev[m] > width:
+                n_cand, width = m, float(ev[m - 1] - ev[m])
+        macro = None
+        if n_states > n_cand:
+            try:
+                chi_soft = pcca_memberships(T, n_cand)
+                lab_m = np.argmax(chi_soft, axis=1)
+                pops = np.asarray([pi[lab_m == u].sum() for u in np.unique(lab_m)])
+                ranks = np.empty(pops.size, dtype=int)
+                ranks[np.argsort(-pops, kind="stable")] = np.arange(pops.size)
+                macro = ranks[np.searchsorted(np.unique(lab_m), lab_m)]
+            except ValueError:
+                macro = None
+        worst = 0.0
+        if macro is not None:
+            out["n_macro"] = n_cand
+            chi = np.zeros((n_states, n_cand))
+            chi[np.arange(n_states), macro] = 1.0
+            for h in horizons:
+                num = chi.T @ np.diag(pi) @ np.linalg.matrix_power(T, h) @ chi
+                den = chi.T @ np.diag(pi) @ chi + np.eye(n_cand) * NUMERIC_MIN_POSITIVE
+                pred = num @ np.linalg.inv(den)
+                obs = _rownorm_strict(_pair_counts([np.where(np.asarray(t) >= 0, macro[np.asarray(t)], -1) for t in dtrajs],
+                                                   n_cand, lag * h))
+                worst = max(worst, np.abs(pred - obs).sum() / np.abs(obs).sum())
+        else:
+            for h in horizons:
+                pred = np.linalg.matrix_power(T, h)
+                obs = _rownorm_strict(_pair_counts(dtrajs, n_states, lag * h))
+                worst = max(worst, np.abs(pred - obs).sum() / np.abs(obs).sum())
+        out["ck_error"] = float(worst)
+    except Exception:
+        return out
+    try:
+        _, slab = connected_components((C > 0).astype(int), directed=True, connection="strong", return_labels=True)
+        act = np.flatnonzero(slab == np.argmax(np.bincount(slab)))
+        Tr, _, _ = reversible_mle(C[np.ix_(act, act)])
+        w = np.sort(np.abs(np.linalg.eigvals(Tr)))[::-1][1:11]
+        out["timescales"] = -lag / np.log(np.clip(w, NUMERIC_MIN_POSITIVE, 1 - NUMERIC_MIN_POSITIVE))
+        out["diag_mass"] = float(np.trace(Tr) / act.size)
+    except Exception:
+        pass
+    out["passed"] = bool(np.isfinite(out["diag_mass"]) and out["diag_mass"] >= diag_mass_threshold)
+    return out
+
+
+def ck_its_select(evals, tau_candidates, ck_threshold=0.15):
+    for e in sorted(evals, key=lambda e: e["lag"]):
+        if e["passed"] and e["ck_error"] <= ck_threshold:
+            return e["lag"]
+    ok = [e for e in evals if e["passed"]]
+    if ok:
+        return min(ok, key=lambda e: e["ck_error"])["lag"]
+    return min(tau_candidates)

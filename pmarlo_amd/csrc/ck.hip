@@ -82,6 +82,28 @@ __global__ __launch_bounds__(1024) void mse_kernel(const double* __restrict__ P,
     if (threadIdx.x == 0) out[0] = t / ((double)n * (double)n);
 }
 
+// out = { sum |P - Q|, sum |Q|, sum (P - Q)^2 } over n x m entries, fixed summation order
+__global__ __launch_bounds__(1024) void diff_norms_kernel(const double* __restrict__ P, int64_t ldp,
+                                                          const double* __restrict__ Q, int64_t ldq, int n, int m,
+                                                          double* __restrict__ out) {
+    __shared__ double red[16];
+    double l1 = 0.0, ref = 0.0, l2 = 0.0;
+    for (int64_t e = threadIdx.x; e < (int64_t)n * m; e += blockDim.x) {
+        const int i = (int)(e / m), j = (int)(e - (int64_t)i * m);
+        const double q = Q[(size_t)i * ldq + j];
+        const double d = P[(size_t)i * ldp + j] - q;
+        l1 += fabs(d);
+        ref += fabs(q);
+        l2 = fma(d, d, l2);
+    }
+    l1 = block_sum_1024(l1, red);
+    __syncthreads();
+    ref = block_sum_1024(ref, red);
+    __syncthreads();
+    l2 = block_sum_1024(l2, red);
+    if (threadIdx.x == 0) { out[0] = l1; out[1] = ref; out[2] = l2; }
+}
+
 // out[0] = sqrt(mean_i( sum_j p_ij (1 - p_ij) / N_i / n )),  N_i <= 0 or non-finite -> 1
 __global__ __launch_bounds__(1024) void multinomial_se_kernel(const double* __restrict__ P, int64_t ldp,
                                                               const double* __restrict__ rowcounts, int n,
@@ -168,6 +190,16 @@ msm_status msm_ck_test(msm_ctx* ctx, const double* d_T1, int64_t ld1, const doub
             }
         }
     }
+    return MSM_OK;
+}
+
+msm_status msm_diff_norms(msm_ctx* ctx, const double* d_P, int64_t ldp, const double* d_Q, int64_t ldq, int n, int m,
+                          double* d_out) {
+    if (!ctx) return MSM_ERR_INVALID;
+    MSM_REQUIRE(ctx, d_P && d_Q && d_out, "msm_diff_norms: null pointer");
+    MSM_REQUIRE(ctx, n >= 1 && m >= 1 && ldp >= m && ldq >= m, "msm_diff_norms: bad shape");
+    hipLaunchKernelGGL(diff_norms_kernel, dim3(1), dim3(1024), 0, ctx->stream, d_P, ldp, d_Q, ldq, n, m, d_out);
+    MSM_CHECK_LAUNCH(ctx);
     return MSM_OK;
 }
 

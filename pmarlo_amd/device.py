@@ -749,6 +749,13 @@ class Engine:
                                      pi.ptr, ctypes.byref(it), ctypes.byref(err)), self.handle)
         return {"T": T, "pi": pi, "iterations": it.value, "err": err.value}
 
+    def diff_norms(self, P: DeviceArray, Q: DeviceArray) -> np.ndarray:
+        """[sum |P - Q|, sum |Q|, sum (P - Q)^2] of two f64 matrices of one shape."""
+        n, m = P.shape
+        out = self.empty((3,), np.float64)
+        check(lib.msm_diff_norms(self.handle, P.ptr, m, Q.ptr, Q.shape[1], n, m, out.ptr), self.handle)
+        return out.to_host()
+
     def philox4x32(self, key: int, counter) -> np.ndarray:
         import ctypes
 
