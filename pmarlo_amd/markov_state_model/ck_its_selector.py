@@ -139,10 +139,13 @@ def _reversible_summary(eng, C: np.ndarray, lag: int, n_ts: int = 10):
     out = eng.reversible_mle(eng.to_device(sub))
     n = act.size
     want = int(min(n_ts, n - 1))
-    spec = eng.spectrum(out["T"], n_its=want, lags=[float(lag)], want_pi=False, allow_unconverged=True)
-    # deeptime's timescales(): -lag / ln|lambda_i| of the non-unit eigenvalues, slowest first
+    spec = eng.spectrum(out["T"], n_its=0, n_watch=want + 1, want_pi=False, allow_unconverged=True)
+    # deeptime's timescales(): -lag / ln|lambda_i| of the non-unit eigenvalues in descending magnitude
+    mag = np.abs(spec["ritz"][0][1:1 + want])
+    with np.errstate(divide="ignore", invalid="ignore"):
+        ts = -float(lag) / np.log(np.clip(mag, _EPS, 1.0 - _EPS))
     diag = float(np.trace(out["T"].to_host()) / n)
-    return np.asarray(spec["its_ts"][0], dtype=float), diag
+    return np.asarray(ts, dtype=float), diag
 
 
 def _evaluate_lag(tr: _Trajectories, lag: int, horizons: List[int], C_by_lag: dict, coverage_threshold: float,

@@ -48,8 +48,10 @@ def _compare(res: LagEvaluationResult, want: dict):
 def test_microstate_route_matches_oracle(engine):
     trajs = [_chain([6, 5, 5, 4], 40_000, s) for s in (1, 2)]
     taus, horizons = [1, 2, 5, 10], [1, 2, 3]
-    lag, evals = select_optimal_lag_ck_its(trajs, tau_candidates=taus, horizons=horizons, min_median_count=50)
-    want = [npport.ck_its_evaluate_lag(trajs, t, horizons, 20, min_median_count=50) for t in taus]
+    lag, evals = select_optimal_lag_ck_its(trajs, tau_candidates=taus, horizons=horizons, min_median_count=50,
+                                           diag_mass_threshold=0.1)
+    want = [npport.ck_its_evaluate_lag(trajs, t, horizons, 20, min_median_count=50, diag_mass_threshold=0.1)
+            for t in taus]
     assert [e.lag for e in evals] == taus
     for e, w in zip(evals, want):
         assert w["n_macro"] == 0                  # raw counts: no detailed balance, PCCA+ declines
@@ -63,8 +65,9 @@ def test_macrostate_route_on_reversible_counts(engine):
     trajs = [x, x[::-1].copy()]                    # a trajectory and its reversal: symmetric counts exactly
     taus, horizons = [1, 3], [1, 2, 4]
     lag, evals = select_optimal_lag_ck_its(trajs, tau_candidates=taus, horizons=horizons, min_median_count=10,
-                                           ck_threshold=10.0)
-    want = [npport.ck_its_evaluate_lag(trajs, t, horizons, 18, min_median_count=10) for t in taus]
+                                           ck_threshold=10.0, diag_mass_threshold=0.05)
+    want = [npport.ck_its_evaluate_lag(trajs, t, horizons, 18, min_median_count=10, diag_mass_threshold=0.05)
+            for t in taus]
     for e, w in zip(evals, want):
         assert w["n_macro"] == 3                   # eigenvalue gap after the three metastable sets
         _compare(e, w)
