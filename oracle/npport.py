@@ -1016,3 +1016,49 @@ def ck_its_select(evals, tau_candidates, ck_threshold=0.15):
     if ok:
         return min(ok, key=lambda e: e["ck_error"])["lag"]
     return min(tau_candidates)
+
+
+def ck_macro(dtrajs, lag_time, macro_k=4, factors=(2, 3, 4, 5), min_trans=50):
+    """Macrostate branch of run_ck (S/markov_state_model/ck_runner.py:178-213): PCCA+ on the lag-1 matrix of
+    the connected microstates, trajectories mapped to macrostates, mse[f] = mean((T1^f - T_f)^2).
+    Returns None when the branch declines (too few states, gap < 0.01, PCCA+ refuses, thin rows)."""
+    n_states = int(max(int(np.max(t)) for t in dtrajs) + 1)
+    C1 = _pair_counts(dtrajs, n_states, 1)
+    active = np.where(C1.sum(axis=1) + C1.sum(axis=0) > 0)[0]
+    lut = -np.ones(n_states, dtype=np.int64)
+    lut[active] = np.arange(active.size)
+    trajs = [lut[np.asarray(t)][lut[np.asarray(t)] >= 0] for t in dtrajs]
+    n = active.size
+    if n <= macro_k:
+        return None
+    T1 = _pair_counts(trajs, n, 1)
+    T1 = T1 / np.where(T1.sum(1, keepdims=True) == 0, 1.0, T1.sum(1, keepdims=True))
+    ev = np.sort(np.real(np.linalg.eigvals(T1)))[::-1]
+    if ev.size <= macro_k or ev[macro_k - 1] - ev[macro_k] < 0.01:
+        return None
+    try:
+        chi = pcca_memberships(T1, macro_k)
+    except ValueError:
+        return None
+    lab = np.argmax(chi, axis=1)
+    pi = stationary_distribution(T1)
+    uniq = np.unique(lab)
+    pops = np.asarray([pi[lab == u].sum() for u in uniq])
+    ranks = np.empty(uniq.size, dtype=int)
+    ranks[np.argsort(-pops, kind="stable")] = np.arange(uniq.size)
+    macro = ranks[np.searchsorted(uniq, lab)]
+    m = int(macro.max()) + 1
+    mtr = [macro[t] for t in trajs]
+    Cm = _pair_counts(mtr, m, lag_time)
+    if not np.all(Cm.sum(axis=1) >= min_trans):
+        return None
+    Tm = Cm / Cm.sum(1, keepdims=True)
+    out = {"mse": {}, "insufficient_k": [int(f) for f in factors], "macro": macro, "active": active}
+    for f in factors:
+        Ck = _pair_counts(mtr, m, lag_time * int(f))
+        if np.any(Ck.sum(axis=1) < min_trans):
+            continue
+        d = np.linalg.matrix_power(Tm, int(f)) - Ck / Ck.sum(1, keepdims=True)
+        out["mse"][int(f)] = float(np.mean(d * d))
+        out["insufficient_k"].remove(int(f))
+    return out

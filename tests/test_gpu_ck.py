@@ -89,3 +89,39 @@ def test_run_ck_insufficient_and_errors():
         run_ck(dtrajs, 0)
     with pytest.raises(ValueError):
         run_ck(dtrajs, 1, factors=(1,))
+
+
+def test_run_ck_macro_branch_on_reversible_counts():
+    """A trajectory plus its time reversal has exactly symmetric counts, so the lag-1 matrix satisfies
+    detailed balance and PCCA+ accepts it: the macrostate branch runs (ck_runner.py:178-213)."""
+    rng = np.random.default_rng(12)
+    sizes = [6, 5, 4, 3]
+    k = sum(sizes)
+    W = rng.random((k, k)) * 0.004
+    o = 0
+    for s in sizes:
+        W[o:o + s, o:o + s] += rng.random((s, s)) + 0.2
+        o += s
+    W = W + W.T
+    cdf = np.cumsum(W / W.sum(1, keepdims=True), axis=1)
+    x = np.zeros(80_000, dtype=np.int64)
+    u = rng.random(x.size)
+    for t in range(1, x.size):
+        x[t] = min(k - 1, int(np.searchsorted(cdf[x[t - 1]], u[t])))
+    dtrajs = [x + 2, (x + 2)[::-1].copy()]                      # ids 0, 1 unused
+    want = npport.ck_macro(dtrajs, 3, macro_k=4, factors=(2, 3, 4), min_trans=50)
+    assert want is not None
+    got = run_ck(dtrajs, 3, macro_k=4, min_trans=50, factors=(2, 3, 4))
+    assert got.mode == "macro"
+    np.testing.assert_array_equal(got.macro_labels, want["macro"])
+    np.testing.assert_array_equal(got.selected_states, want["active"])
+    assert sorted(got.mse) == sorted(want["mse"]) == [2, 3, 4] and got.insufficient_k == []
+    for f, v in want["mse"].items():
+        np.testing.assert_allclose(got.mse[f], v, rtol=1e-9)
+    truth = np.repeat(np.arange(4), sizes)
+    for b in range(4):
+        assert np.unique(got.macro_labels[truth == b]).size == 1
+    # without detailed balance the same data falls through to the microstate branch
+    assert run_ck([x], 3, macro_k=4, min_trans=50, factors=(2,)).mode == "micro"
+    # more macrostates than the spectrum supports: the gap test (< 0.01 is rare here) or PCCA+ decides; k <= macro_k skips
+    assert run_ck(dtrajs, 3, macro_k=40, min_trans=50, factors=(2,)).mode == "micro"
