@@ -1062,3 +1062,33 @@ def ck_macro(dtrajs, lag_time, macro_k=4, factors=(2, 3, 4, 5), min_trans=50):
         out["mse"][int(f)] = float(np.mean(d * d))
         out["insufficient_k"].remove(int(f))
     return out
+
+
+# ---- VAMP reduction (S/markov_state_model/reduction.py:113-148; deeptime VAMP restated) ------------
+def vamp_reduce(X, lag=1, n_components=2, scale=True, epsilon=1e-6):
+    """_preprocess, then the left singular functions of the whitened cross-covariance
+    (Wu & Noe 2020): window means removed, 1/T normalisation, eigenvalues <= epsilon dropped, every
+    component's largest-magnitude loading positive.  Returns (Y, singular_values)."""
+    Z = preprocess(np.asarray(X), scale=scale)
+    A, B = Z[:-lag], Z[lag:]
+    T = A.shape[0]
+    a0, b0 = A.mean(axis=0), B.mean(axis=0)
+    Ac, Bc = A - a0, B - b0
+    C00, Ctt, C0t = Ac.T @ Ac / T, Bc.T @ Bc / T, Ac.T @ Bc / T
+
+    def inv_split(C):
+        w, V = np.linalg.eigh(0.5 * (C + C.T))
+        w, V = w[::-1], V[:, ::-1]
+        keep = w > epsilon
+        V = V[:, keep]
+        for j in range(V.shape[1]):
+            V[:, j] *= np.sign(V[np.argmax(np.abs(V[:, j])), j])
+        return V / np.sqrt(w[keep])
+
+    L0, Lt = inv_split(C00), inv_split(Ctt)
+    U, s, _ = np.linalg.svd(L0.T @ C0t @ Lt)
+    dim = min(n_components, L0.shape[1], Lt.shape[1])
+    W = L0 @ U[:, :dim]
+    for j in range(dim):
+        W[:, j] *= np.sign(W[np.argmax(np.abs(W[:, j])), j])
+    return (Z - a0) @ W, s

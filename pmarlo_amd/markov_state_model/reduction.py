@@ -11,7 +11,8 @@ import numpy as np
 from ..device import get_engine
 from ..pipeline import MSMPipeline, TicaModel
 
-__all__ = ["tica_reduce", "pca_reduce", "reduce_features", "tica_fit_transform_trajectories", "preprocess_params"]
+__all__ = ["tica_reduce", "pca_reduce", "vamp_reduce", "reduce_features", "tica_fit_transform_trajectories",
+           "preprocess_params"]
 
 
 def _as_matrix(X) -> np.ndarray:
@@ -86,17 +87,79 @@ def pca_reduce(X: np.ndarray, n_components: int = 2, batch_size: Optional[int] =
     return np.asarray(Y.to_host(), dtype=float)
 
 
+def _whitener(eng, C: np.ndarray, epsilon: float) -> np.ndarray:
+    """deeptime's spd_inv_split: C = V S V' (device Jacobi), keep s > epsilon, L = V S^-1/2 with the
+    largest-magnitude entry of every column made positive."""
+    w, V, _ = eng.eigh(eng.to_device(0.5 * (C + C.T)))
+    w, V = w.to_host(), V.to_host()
+    order = np.argsort(-w, kind="stable")
+    w, V = w[order], V[:, order]
+    keep = w > epsilon
+    if not keep.any():
+        raise ValueError("VAMP: covariance matrix has zero rank")
+    V = V[:, keep]
+    V = V * np.sign(V[np.argmax(np.abs(V), axis=0), np.arange(V.shape[1])])[None, :]
+    return V / np.sqrt(w[keep])[None, :]
+
+
+def vamp_reduce(X: np.ndarray, lag: int = 1, n_components: int = 2, scale: bool = True,
+                epsilon: float = 1e-6) -> np.ndarray:
+    """_preprocess + deeptime VAMP(lagtime, dim, epsilon).fit([X_prep]).transform(X_prep)
+    (S/markov_state_model/reduction.py:113-148), restated from the published estimator (Wu & Noe,
+    J. Nonlinear Sci. 30, 2020; deeptime 0.4.5 is absent: parity unpinned):
+
+      C00 = cov(X[:-lag]), Ctt = cov(X[lag:]), C0t = cross-covariance (window means removed, 1/T),
+      K = L0' C0t Lt with the whiteners L = V S^-1/2 of C00 / Ctt (eigenvalues <= epsilon dropped),
+      K = U' S W'; the transform is the left singular functions (x - mean0) L0 U'[:, :dim].
+
+    On the device: both moment passes over the frames (fp64 matrix cores), the Jacobi eigensolves of C00,
+    Ctt and K K', the projection of all frames.  The F x F glue between them is host arithmetic.  Signs:
+    the largest-magnitude loading of every component is positive (LAPACK's SVD signs are arbitrary)."""
+    Xm = _as_matrix(X)
+    n, F = Xm.shape
+    lag = int(lag)
+    if lag < 1 or n <= lag:
+        raise ValueError(f"VAMP needs 1 <= lag < n_frames (lag={lag}, n_frames={n})")
+    eng = get_engine()
+    pipe = MSMPipeline(eng)
+    xd = eng.to_device(Xm)
+    mu, sigma, inv_sigma, has_nan = pipe.standardise_params(xd, scale=scale)
+    both = pipe.tica_moments(xd, lag, mu, assume_finite=not has_nan).to_host()
+    head = pipe.tica_moments(xd, 0, mu, segments=[(0, n - lag)], assume_finite=not has_nan).to_host()
+    sd = sigma.to_host()
+    T = float(both[-1])
+    S00 = 0.5 * head[:F * F].reshape(F, F)                       # sum over X[:-lag] of z z'
+    Stt = both[:F * F].reshape(F, F) - S00                       # the remainder: sum over X[lag:]
+    S0t = both[F * F:2 * F * F].reshape(F, F)
+    m0 = both[2 * F * F:2 * F * F + F] / T
+    mt = both[2 * F * F + F:2 * F * F + 2 * F] / T
+    norm = np.outer(sd, sd)
+    C00 = (S00 / T - np.outer(m0, m0)) / norm
+    Ctt = (Stt / T - np.outer(mt, mt)) / norm
+    C0t = (S0t / T - np.outer(m0, mt)) / norm
+    L0, Lt = _whitener(eng, C00, epsilon), _whitener(eng, Ctt, epsilon)
+    K = L0.T @ C0t @ Lt
+    w, U, _ = eng.eigh(eng.to_device(np.ascontiguousarray(K @ K.T)))      # left singular vectors of K
+    order = np.argsort(-w.to_host(), kind="stable")
+    dim = int(min(n_components, L0.shape[1], Lt.shape[1]))
+    comps = L0 @ U.to_host()[:, order[:dim]]
+    comps = comps * np.sign(comps[np.argmax(np.abs(comps), axis=0), np.arange(dim)])[None, :]
+    Wfull = np.zeros((F, F))
+    Wfull[:, :dim] = comps
+    Y = eng.project(xd, mu, inv_sigma, eng.to_device(Wfull), dim, mean2=eng.to_device(m0 / sd))
+    return np.asarray(Y.to_host(), dtype=float)
+
+
 def reduce_features(X: np.ndarray, method: str = "pca", n_components: int = 2, lag: int = 1, scale: bool = True,
                     **kwargs) -> np.ndarray:
-    """Unified interface (reduction.py:152-197): "pca" (default, as in the reference), "tica"; "vamp" needs
-    deeptime's estimator and is not available."""
+    """Unified interface (reduction.py:152-197): "pca" (default, as in the reference), "tica", "vamp"."""
     method = str(method).lower()
     if method == "pca":
         return pca_reduce(X, n_components=n_components, scale=scale, **kwargs)
     if method == "tica":
         return tica_reduce(X, lag=lag, n_components=n_components, scale=scale, **kwargs)
     if method == "vamp":
-        raise NotImplementedError("'vamp' is outside the accelerated path (PCA and TICA only)")
+        return vamp_reduce(X, lag=lag, n_components=n_components, scale=scale, **kwargs)
     raise ValueError(f"Unknown reduction method: {method}")
 
 

@@ -365,3 +365,26 @@ def test_pca_reduce_vs_reference_golden_and_oracle(engine, golden):
         reduce_features(X[:100], method="umap")
     with pytest.raises(ValueError):
         pca_reduce(X[:100], n_components=65)
+
+
+# ---- VAMP reduction (reduction.vamp_reduce; deeptime absent -> oracle restatement) ---------------
+@pytest.mark.parametrize("n,F,lag,dim,scale", [(20_000, 8, 5, 3, True), (6_000, 20, 1, 4, False), (3_000, 3, 10, 5, True)])
+def test_vamp_reduce_vs_oracle(engine, n, F, lag, dim, scale):
+    from pmarlo_amd.markov_state_model import reduce_features, vamp_reduce
+
+    X = _gen.correlated_series(n, F, seed=n + F).astype(np.float64)
+    X *= np.linspace(0.5, 3.0, F)[None, :]
+    X[::97, 1] = np.nan                                         # imputed to the column mean by _preprocess
+    got = vamp_reduce(X, lag=lag, n_components=dim, scale=scale)
+    want, s = npport.vamp_reduce(X, lag=lag, n_components=dim, scale=scale)
+    assert got.shape == want.shape == (n, min(dim, F))
+    np.testing.assert_allclose(got, want, rtol=0, atol=2e-8 * np.abs(want).max())
+    # the instantaneous window is whitened by construction
+    C = np.cov(got[:-lag].T, bias=True)
+    np.testing.assert_allclose(C, np.eye(got.shape[1]), atol=1e-8)
+    # leading singular values of an AR(1) mixture: the latent autocorrelations at this lag
+    if (n, F) == (20_000, 8):
+        assert abs(s[0] - 0.985 ** lag) < 0.06 and abs(s[1] - 0.95 ** lag) < 0.08 and s[2] < 0.2
+    np.testing.assert_array_equal(reduce_features(X, method="vamp", n_components=dim, lag=lag, scale=scale), got)
+    with pytest.raises(ValueError):
+        vamp_reduce(X[:5], lag=10)
