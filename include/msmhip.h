@@ -235,10 +235,13 @@ msm_status msm_tica_solve(msm_ctx* ctx, const double* d_moments, const double* d
 /* Y[t][c] = sum_f (((x[t][f] - mu[f]) * inv_sigma[f]) - mean2[f]) * W[f][c], fp64 FMA chain
  * over ascending f.  Replaces model.transform(X_prep) of tica_reduce
  * (S/markov_state_model/reduction.py:109).  NaN -> 0 after centring.
- * d_mean2 may be NULL.  W is [F, ldw] (first d columns used), Y is [n, ldy] f64. */
+ * d_mean2 may be NULL.  W is [F, ldw] (first d columns used), Y is [n, ldy] f64.
+ * d_absmax (f64 [1], may be NULL) receives max |Y| from the same pass: pointing it at slot 2 of a
+ * k-means fit state and calling msm_kmeans_fit_begin with absmax_ready = 1 saves that call's own
+ * pass over Y. */
 msm_status msm_project(msm_ctx* ctx, const void* d_x, msm_dtype dtype, int64_t n, int F, int64_t ld,
                        const double* d_mu, const double* d_inv_sigma, const double* d_mean2,
-                       const double* d_w, int d, int64_t ldw, double* d_y, int64_t ldy);
+                       const double* d_w, int d, int64_t ldw, double* d_y, int64_t ldy, double* d_absmax);
 
 /* Symmetric eigendecomposition by parallel cyclic Jacobi (n <= 256), ascending
  * eigenvalues d_w [n], eigenvectors in the columns of d_v [n, n] (may be NULL).
@@ -297,6 +300,8 @@ msm_status msm_kmeans_assign(msm_ctx* ctx, const void* d_x, msm_dtype dtype, int
  * msm_kmeans_fit_begin  computes the fixed-point scale from max|z| and n_total (the
  *                       frame count over ALL shards) and, if init_centers != 0, the
  *                       initial centres.  Shards then all-reduce MIN of state[0].
+ *                       absmax_ready != 0: state[2] already holds max|x| (msm_project's d_absmax);
+ *                       only without whitening (d_mean == NULL).
  * msm_kmeans_accumulate adds this shard's member sums / counts into d_sums int64 [k*d],
  *                       d_counts int64 [k] (caller zeroes them; all-reduce SUM across shards).
  * msm_kmeans_update     centres <- sums/counts, shift2, done, n_iter; clear != 0 zeroes
@@ -308,7 +313,7 @@ msm_status msm_kmeans_fit(msm_ctx* ctx, const void* d_x, msm_dtype dtype, int64_
 msm_status msm_kmeans_fit_begin(msm_ctx* ctx, const void* d_x, msm_dtype dtype, int64_t n, int d,
                                 int64_t ld, const double* d_mean, const double* d_std, int k,
                                 uint64_t seed, int init_centers, double n_total, double tol2,
-                                double* d_centers, double* d_state);
+                                double* d_centers, double* d_state, int absmax_ready);
 msm_status msm_kmeans_accumulate(msm_ctx* ctx, const void* d_x, msm_dtype dtype, int64_t n, int d,
                                  int64_t ld, const double* d_centers, int k, const double* d_mean,
                                  const double* d_std, const double* d_state, int64_t* d_sums,

@@ -67,12 +67,12 @@ _PROTOTYPES: dict[str, tuple] = {
     "msm_standardise_params": (_i32, [_vp, _vp, _vp, _i32, _f64, _i32, _vp, _vp, _vp]),
     "msm_lagged_moments": (_i32, [_vp, _vp, _i32, _i64, _i32, _i64, _vp, _vp, _i32, _i32, _vp, _i32, _vp]),
     "msm_tica_solve": (_i32, [_vp, _vp, _vp, _i32, _f64, _i32, _vp, _vp, _vp, _vp]),
-    "msm_project": (_i32, [_vp, _vp, _i32, _i64, _i32, _i64, _vp, _vp, _vp, _vp, _i32, _i64, _vp, _i64]),
+    "msm_project": (_i32, [_vp, _vp, _i32, _i64, _i32, _i64, _vp, _vp, _vp, _vp, _i32, _i64, _vp, _i64, _vp]),
     "msm_eigh": (_i32, [_vp, _vp, _i32, _vp, _vp, _vp]),
     "msm_kmeans_assign": (_i32, [_vp, _vp, _i32, _i64, _i32, _i64, _vp, _i32, _vp, _vp, _vp, _vp]),
     "msm_kmeans_fit": (_i32, [_vp, _vp, _i32, _i64, _i32, _i64, _vp, _vp, _i32, C.c_uint64, _i32, _i32, _f64, _vp, _vp]),
     "msm_kmeans_fit_begin": (
-        _i32, [_vp, _vp, _i32, _i64, _i32, _i64, _vp, _vp, _i32, C.c_uint64, _i32, _f64, _f64, _vp, _vp]),
+        _i32, [_vp, _vp, _i32, _i64, _i32, _i64, _vp, _vp, _i32, C.c_uint64, _i32, _f64, _f64, _vp, _vp, _i32]),
     "msm_kmeans_accumulate": (_i32, [_vp, _vp, _i32, _i64, _i32, _i64, _vp, _i32, _vp, _vp, _vp, _vp, _vp]),
     "msm_kmeans_update": (_i32, [_vp, _vp, _vp, _i32, _i32, _vp, _vp, _i32]),
     "msm_sum_f64": (_i32, [_vp, _vp, _i64, _vp]),

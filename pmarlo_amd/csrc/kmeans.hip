@@ -841,9 +841,10 @@ msm_status msm_kmeans_assign(msm_ctx* ctx, const void* d_x, msm_dtype dtype, int
 
 msm_status msm_kmeans_fit_begin(msm_ctx* ctx, const void* d_x, msm_dtype dtype, int64_t n, int d, int64_t ld,
                                 const double* d_mean, const double* d_std, int k, uint64_t seed, int init_centers,
-                                double n_total, double tol2, double* d_centers, double* d_state) {
+                                double n_total, double tol2, double* d_centers, double* d_state, int absmax_ready) {
     if (!ctx) return MSM_ERR_INVALID;
     MSM_REQUIRE(ctx, n >= 1 && d >= 1 && d <= 256 && k >= 1 && ld >= d, "msm_kmeans_fit_begin: bad shape");
+    MSM_REQUIRE(ctx, !absmax_ready || !d_mean, "msm_kmeans_fit_begin: a precomputed max |x| excludes whitening");
     MSM_REQUIRE(ctx, !init_centers || n >= k, "msm_kmeans_fit_begin: fewer frames (%lld) than centres (%d)",
                 (long long)n, k);
     MSM_REQUIRE(ctx, (d_mean == nullptr) == (d_std == nullptr), "msm_kmeans_fit_begin: mean/std must come together");
@@ -852,15 +853,17 @@ msm_status msm_kmeans_fit_begin(msm_ctx* ctx, const void* d_x, msm_dtype dtype, 
     MSM_REQUIRE(ctx, n_total >= (double)n && tol2 >= 0.0, "msm_kmeans_fit_begin: bad n_total / tol2");
     // d_state doubles as scratch for the absmax bits (slot 2 = absmax)
     unsigned long long* bits = (unsigned long long*)(d_state + 2);
-    MSM_HIP(ctx, hipMemsetAsync(bits, 0, sizeof(unsigned long long), ctx->stream));
-    const int grid = (int)std::min<int64_t>((n * d + kThreads * 8 - 1) / (kThreads * 8), (int64_t)ctx->n_cu * 8);
-    if (dtype == MSM_F32)
-        hipLaunchKernelGGL(absmax_kernel<float>, dim3(grid), dim3(kThreads), 0, ctx->stream, (const float*)d_x, n, d, ld,
-                           d_mean, d_std, bits);
-    else
-        hipLaunchKernelGGL(absmax_kernel<double>, dim3(grid), dim3(kThreads), 0, ctx->stream, (const double*)d_x, n, d,
-                           ld, d_mean, d_std, bits);
-    MSM_CHECK_LAUNCH(ctx);
+    if (!absmax_ready) {   // otherwise msm_project (d_absmax = d_state + 2) left it there while writing d_x
+        MSM_HIP(ctx, hipMemsetAsync(bits, 0, sizeof(unsigned long long), ctx->stream));
+        const int grid = (int)std::min<int64_t>((n * d + kThreads * 8 - 1) / (kThreads * 8), (int64_t)ctx->n_cu * 8);
+        if (dtype == MSM_F32)
+            hipLaunchKernelGGL(absmax_kernel<float>, dim3(grid), dim3(kThreads), 0, ctx->stream, (const float*)d_x, n, d,
+                               ld, d_mean, d_std, bits);
+        else
+            hipLaunchKernelGGL(absmax_kernel<double>, dim3(grid), dim3(kThreads), 0, ctx->stream, (const double*)d_x, n,
+                               d, ld, d_mean, d_std, bits);
+        MSM_CHECK_LAUNCH(ctx);
+    }
     hipLaunchKernelGGL(fit_scale_kernel, dim3(1), dim3(64), 0, ctx->stream, bits, n_total, tol2, (FitState*)d_state);
     MSM_CHECK_LAUNCH(ctx);
     if (init_centers) {
@@ -911,7 +914,7 @@ msm_status msm_kmeans_fit(msm_ctx* ctx, const void* d_x, msm_dtype dtype, int64_
     if (!ctx) return MSM_ERR_INVALID;
     MSM_REQUIRE(ctx, max_iter >= 0, "msm_kmeans_fit: max_iter must be >= 0");
     msm_status rs = msm_kmeans_fit_begin(ctx, d_x, dtype, n, d, ld, d_mean, d_std, k, seed, init_centers, (double)n,
-                                         tol2, d_centers, d_state);
+                                         tol2, d_centers, d_state, 0);
     if (rs != MSM_OK) return rs;
     const size_t acc_bytes = (size_t)k * (d + 1) * sizeof(unsigned long long);
     rs = msm_reserve_scratch(ctx, acc_bytes);

@@ -153,12 +153,29 @@ __global__ void standardise_params_kernel(const double* __restrict__ sums, const
 constexpr int kProjFrames = 64;
 constexpr int kProjFT = 64;  // feature chunk
 
+// Running max |y| of everything a workgroup stored, folded into *bits (the IEEE bit pattern of a
+// non-negative double orders like the integer): one atomic per workgroup, and only when it can raise
+// the maximum.  Feeds the fixed-point scale of the k-means fit without a second pass over Y.
+__device__ __forceinline__ void publish_absmax(double m, unsigned long long* __restrict__ bits, double* red) {
+    if (!bits) return;
+    for (int off = 32; off > 0; off >>= 1) m = fmax(m, __shfl_down(m, off, 64));
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < kThreads / 64; ++w) m = fmax(m, red[w]);
+        const unsigned long long b = (unsigned long long)__double_as_longlong(m);
+        if (b > *bits) atomicMax(bits, b);
+    }
+}
+
 template <typename T>
 __global__ __launch_bounds__(kThreads) void project_kernel(
     const T* __restrict__ x, int64_t n, int F, int64_t ld, const double* __restrict__ mu,
     const double* __restrict__ inv_sigma, const double* __restrict__ m2, const double* __restrict__ W, int d,
-    int64_t ldw, double* __restrict__ y, int64_t ldy) {
+    int64_t ldw, double* __restrict__ y, int64_t ldy, unsigned long long* __restrict__ absmax_bits) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    double amax = 0.0;
     double* zs = reinterpret_cast<double*>(smem_raw);          // [64][FT+1]
     double* ws = zs + kProjFrames * (kProjFT + 1);              // [FT][d]
     const int tid = threadIdx.x;
@@ -205,10 +222,14 @@ __global__ __launch_bounds__(kThreads) void project_kernel(
 #pragma unroll
             for (int ci = 0; ci < kMaxCols; ++ci) {
                 const int c = cg + 4 * ci;
-                if (c < d) y[(t0 + r) * ldy + c] = acc[ci];
+                if (c < d) {
+                    y[(t0 + r) * ldy + c] = acc[ci];
+                    amax = fmax(amax, fabs(acc[ci]));
+                }
             }
         }
     }
+    publish_absmax(amax, absmax_bits, zs);
 }
 
 // ---------------------------------------------------------------------------
@@ -231,8 +252,9 @@ template <typename T, bool VEC>
 __global__ __launch_bounds__(kThreads) void project_mfma_kernel(
     const T* __restrict__ x, int64_t n, int F, int64_t ld, const double* __restrict__ mu,
     const double* __restrict__ inv_sigma, const double* __restrict__ m2, const double* __restrict__ W, int d,
-    int64_t ldw, double* __restrict__ y, int64_t ldy) {
+    int64_t ldw, double* __restrict__ y, int64_t ldy, unsigned long long* __restrict__ absmax_bits) {
     extern __shared__ __attribute__((aligned(16))) unsigned char proj_smem[];
+    double amax = 0.0;
     double* wl = reinterpret_cast<double*>(proj_smem);  // [F16][16]
     const int F16 = (F + 15) & ~15;
     double* mul = wl + (size_t)F16 * 16;  // [F16]
@@ -268,7 +290,10 @@ __global__ __launch_bounds__(kThreads) void project_mfma_kernel(
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int c = g + 4 * r;
-                if (c < d) y[t * ldy + c] = acc[r];
+                if (c < d) {
+                    y[t * ldy + c] = acc[r];
+                    amax = fmax(amax, fabs(acc[r]));
+                }
             }
         }
     };
@@ -350,6 +375,7 @@ __global__ __launch_bounds__(kThreads) void project_mfma_kernel(
             store(grp, acc);
         }
     }
+    publish_absmax(amax, absmax_bits, wl);
 }
 
 int pick_tf(int F) {
@@ -433,9 +459,11 @@ msm_status msm_column_moments(msm_ctx* ctx, const void* d_x, msm_dtype dtype, in
 
 msm_status msm_project(msm_ctx* ctx, const void* d_x, msm_dtype dtype, int64_t n, int F, int64_t ld,
                        const double* d_mu, const double* d_inv_sigma, const double* d_mean2, const double* d_w, int d,
-                       int64_t ldw, double* d_y, int64_t ldy) {
+                       int64_t ldw, double* d_y, int64_t ldy, double* d_absmax) {
     if (!ctx) return MSM_ERR_INVALID;
     MSM_REQUIRE(ctx, n >= 0 && F >= 1 && d >= 1 && d <= 64, "msm_project: need n >= 0, F >= 1, 1 <= d <= 64");
+    unsigned long long* bits = reinterpret_cast<unsigned long long*>(d_absmax);
+    if (bits) MSM_HIP(ctx, hipMemsetAsync(bits, 0, sizeof(unsigned long long), ctx->stream));
     MSM_REQUIRE(ctx, ld >= F && ldw >= d && ldy >= d, "msm_project: bad leading dimension");
     MSM_REQUIRE(ctx, dtype == MSM_F32 || dtype == MSM_F64, "msm_project: bad dtype");
     if (n == 0) return MSM_OK;
@@ -449,7 +477,7 @@ msm_status msm_project(msm_ctx* ctx, const void* d_x, msm_dtype dtype, int64_t n
         const bool vec = (F % 16 == 0) && (ld % 4 == 0) && (((uintptr_t)d_x) % (4 * esz) == 0);
 #define MSM_PROJ(T, V)                                                                                         \
         hipLaunchKernelGGL((project_mfma_kernel<T, V>), dim3(grid), dim3(kThreads), plds, ctx->stream, (const T*)d_x, n, \
-                           F, ld, d_mu, d_inv_sigma, d_mean2, d_w, d, ldw, d_y, ldy)
+                           F, ld, d_mu, d_inv_sigma, d_mean2, d_w, d, ldw, d_y, ldy, bits)
         if (dtype == MSM_F32) { if (vec) MSM_PROJ(float, true); else MSM_PROJ(float, false); }
         else { if (vec) MSM_PROJ(double, true); else MSM_PROJ(double, false); }
 #undef MSM_PROJ
@@ -467,10 +495,10 @@ msm_status msm_project(msm_ctx* ctx, const void* d_x, msm_dtype dtype, int64_t n
     }
     if (dtype == MSM_F32)
         hipLaunchKernelGGL(project_kernel<float>, dim3(grid), dim3(kThreads), lds, ctx->stream, (const float*)d_x, n, F,
-                           ld, d_mu, d_inv_sigma, d_mean2, d_w, d, ldw, d_y, ldy);
+                           ld, d_mu, d_inv_sigma, d_mean2, d_w, d, ldw, d_y, ldy, bits);
     else
         hipLaunchKernelGGL(project_kernel<double>, dim3(grid), dim3(kThreads), lds, ctx->stream, (const double*)d_x, n,
-                           F, ld, d_mu, d_inv_sigma, d_mean2, d_w, d, ldw, d_y, ldy);
+                           F, ld, d_mu, d_inv_sigma, d_mean2, d_w, d, ldw, d_y, ldy, bits);
     MSM_CHECK_LAUNCH(ctx);
     return MSM_OK;
 }

@@ -380,13 +380,15 @@ class Engine:
         return eig, W, mean, rank
 
     def project(self, x: DeviceArray, mu: DeviceArray, inv_sigma: DeviceArray, W: DeviceArray, d: int, *,
-                mean2: DeviceArray | None = None, out: DeviceArray | None = None) -> DeviceArray:
+                mean2: DeviceArray | None = None, out: DeviceArray | None = None,
+                absmax: DeviceArray | None = None) -> DeviceArray:
+        """`absmax` (one f64, e.g. slot 2 of a k-means fit state) receives max |Y| from the same pass."""
         n, F = x.shape
         ldw = W.shape[1]
         out = out if out is not None else self.empty((n, d), np.float64)
         check(lib.msm_project(self.handle, x.ptr, _dtype_code(x.dtype), n, F, F, mu.ptr, inv_sigma.ptr,
                               mean2.ptr if mean2 is not None else None, W.ptr, int(d), ldw, out.ptr,
-                              out.shape[1]), self.handle)
+                              out.shape[1], absmax.ptr if absmax is not None else None), self.handle)
         return out
 
     def eigh(self, a: DeviceArray, want_vectors: bool = True):
@@ -435,15 +437,17 @@ class Engine:
 
     def kmeans_fit_begin(self, x: DeviceArray, k: int, *, seed: int, n_total: int, tol2: float,
                          mean: DeviceArray | None = None, std: DeviceArray | None = None,
-                         centers: DeviceArray | None = None, init_centers: bool = True):
+                         centers: DeviceArray | None = None, init_centers: bool = True,
+                         state: DeviceArray | None = None, absmax_ready: bool = False):
+        """absmax_ready: slot 2 of `state` already holds max |x| (left there by project(absmax=...))."""
         n, d = x.shape
         centers = centers if centers is not None else self.empty((k, d), np.float64)
-        state = self.zeros((8,), np.float64)
+        state = state if state is not None else self.zeros((8,), np.float64)
         check(lib.msm_kmeans_fit_begin(self.handle, x.ptr, _dtype_code(x.dtype), n, d, d,
                                        mean.ptr if mean is not None else None,
                                        std.ptr if std is not None else None, int(k), int(seed) & (2**64 - 1),
-                                       int(bool(init_centers)), float(n_total), float(tol2), centers.ptr, state.ptr),
-              self.handle)
+                                       int(bool(init_centers)), float(n_total), float(tol2), centers.ptr, state.ptr,
+                                       int(bool(absmax_ready))), self.handle)
         return centers, state
 
     def kmeans_accumulate(self, x: DeviceArray, centers: DeviceArray, state: DeviceArray, sums: DeviceArray,

@@ -182,10 +182,12 @@ class ShardedMSM:
         check(lib.msm_tica_solve(eng.handle, b["lagged"].ptr, self.scale.ptr, F, 1e-6, 1, self.eig.ptr, self.W.ptr,
                                  self.m2.ptr, self.rank_d.ptr), eng.handle)
         # 3. projection
-        eng.project(self.x, self.mean, self.inv_scale, self.W, d, mean2=self.m2, out=self.Y)
+        # max |Y| (the fixed-point scale of the Lloyd sums needs it) falls out of the same pass
+        eng.project(self.x, self.mean, self.inv_scale, self.W, d, mean2=self.m2, out=self.Y,
+                    absmax=b["fit_state"].view((1,), offset_elems=2))
         # 4. k-means: fixed number of Lloyd iterations over all frames
         check(lib.msm_kmeans_fit_begin(eng.handle, self.Y.ptr, 1, cfg.n_frames, d, d, None, None, k, cfg.seed, 1,
-                                       float(self.n_total), 0.0, b["centers"].ptr, b["fit_state"].ptr), eng.handle)
+                                       float(self.n_total), 0.0, b["centers"].ptr, b["fit_state"].ptr, 1), eng.handle)
         if multi:
             # identical start on every rank: rank 0's centres; the coarsest fixed-point scale
             # (state = {scale, inv_scale, ...}: MIN of scale, inv_scale follows as MAX)

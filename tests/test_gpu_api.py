@@ -359,8 +359,6 @@ def test_pca_reduce_vs_reference_golden_and_oracle(engine, golden):
     np.testing.assert_allclose(got, want, rtol=0, atol=1e-8 * np.abs(want).max())
     with pytest.raises(NotImplementedError):
         pca_reduce(X[:100], batch_size=10)
-    with pytest.raises(NotImplementedError):
-        reduce_features(X[:100], method="vamp")
     with pytest.raises(ValueError):
         reduce_features(X[:100], method="umap")
     with pytest.raises(ValueError):

@@ -131,3 +131,23 @@ def test_auto_n_states_picks_the_planted_cluster_count(engine):
     assert res2.rationale == "auto-override=9" and res2.n_states == 9
     with pytest.raises(ValueError):
         cluster_microstates(X, n_states="auto", silhouette_sample_size=1)
+
+
+def test_project_hands_absmax_to_fit_begin(engine):
+    """msm_project's d_absmax + msm_kmeans_fit_begin(absmax_ready=1) give the same fit state (bit for bit)
+    as fit_begin's own pass over Y, on the matrix-core and the wide (d > 16) projection kernels."""
+    rng = np.random.default_rng(3)
+    for n, F, d in ((50_000, 64, 10), (9_001, 24, 20), (777, 7, 3)):
+        X = rng.normal(size=(n, F)).astype(np.float32) * 3.0
+        X[5, 2] = np.nan
+        xd = engine.to_device(X)
+        mu = engine.to_device(np.nanmean(X.astype(np.float64), axis=0))
+        inv = engine.to_device(1.0 / np.nanstd(X.astype(np.float64), axis=0))
+        W = engine.to_device(rng.normal(size=(F, F)))
+        state = engine.zeros((8,), np.float64)
+        Y = engine.project(xd, mu, inv, W, d, absmax=state.view((1,), offset_elems=2))
+        assert state.to_host()[2] == np.abs(Y.to_host()).max()
+        c1, s1 = engine.kmeans_fit_begin(Y, 5, seed=1, n_total=n, tol2=0.0, state=state, absmax_ready=True)
+        c2, s2 = engine.kmeans_fit_begin(Y, 5, seed=1, n_total=n, tol2=0.0)
+        np.testing.assert_array_equal(s1.to_host(), s2.to_host())
+        np.testing.assert_array_equal(c1.to_host(), c2.to_host())

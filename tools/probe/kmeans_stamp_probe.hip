@@ -15,7 +15,7 @@ int main(int argc, char** argv) {
     double *dY, *dC, *dS; int64_t *dsum, *dcnt;
     hipMalloc(&dY, n * d * 8); hipMalloc(&dC, k * d * 8); hipMalloc(&dS, 64); hipMalloc(&dsum, k * d * 8); hipMalloc(&dcnt, k * 8);
     hipMemcpy(dY, Y.data(), n * d * 8, hipMemcpyHostToDevice);
-    if (msm_kmeans_fit_begin(ctx, dY, MSM_F64, n, d, d, nullptr, nullptr, k, 7, 1, (double)n, 0.0, dC, dS)) { printf("%s\n", msm_last_error(ctx)); return 1; }
+    if (msm_kmeans_fit_begin(ctx, dY, MSM_F64, n, d, d, nullptr, nullptr, k, 7, 1, (double)n, 0.0, dC, dS, 0)) { printf("%s\n", msm_last_error(ctx)); return 1; }
     hipMemset(dsum, 0, k * d * 8); hipMemset(dcnt, 0, k * 8);
     unsigned long long z[8] = {0};
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
