@@ -218,6 +218,16 @@ msm_status msm_lagged_moments(msm_ctx* ctx, const void* d_x, msm_dtype dtype, in
                               const int64_t* h_seg_start, const int64_t* h_seg_stop, int n_seg, int lag,
                               const double* d_shift, int assume_finite, double* d_moments);
 
+/* The raw column sums msm_column_moments_partial would give ([cnt F][S1 F][S2 F] about d_shift, over every
+ * frame of the segments) derived from the lagged moments of the SAME shift and segments plus the first
+ * and last `lag` frames of each segment: 2 S1 = sx + sy + edges, 2 S2 = diag(M00) + edges^2.  Saves the
+ * separate standardisation pass over X when the covariance pass runs anyway.  Finite data only (the
+ * lagged moments impute NaN as 0 about the shift, which is the column mean only in the two-pass order);
+ * at most 16 segments, lag >= 1.  Additive across shards like the inputs. */
+msm_status msm_moments_from_lagged(msm_ctx* ctx, const void* d_x, msm_dtype dtype, int64_t n, int F, int64_t ld,
+                                   const int64_t* h_seg_start, const int64_t* h_seg_stop, int n_seg, int lag,
+                                   const double* d_shift, const double* d_moments, double* d_sums);
+
 /* TICA solve on the device (deeptime 0.4.5 TICA._decomposition semantics):
  *   mean = (sx+sy)/(2T); C00 = M00/(2T) - mean mean'; C0t = (M0t+M0t')/(2T) - mean mean'
  *   (all divided by d_scale[i]*d_scale[j] when d_scale != NULL, i.e. covariances of

@@ -589,6 +589,51 @@ msm_status dispatch_cov(msm_ctx* ctx, const T* x, int F, int64_t ld, const Frame
 
 }  // namespace
 
+namespace {
+
+struct EdgeSegs {
+    int n;
+    int lag;
+    int64_t start[MSM_SEG_INLINE];
+    int64_t stop[MSM_SEG_INLINE];
+};
+
+// Column sums over ALL frames of the segments from the lagged moments of the same shift:
+// X0 = [s, e - lag) and Yt = [s + lag, e) cover every frame twice except the first / last `lag`
+// frames of a segment, which this kernel adds (segments no longer than the lag lie in both edges
+// entirely): 2 S1 = sx + sy + first + last, 2 S2 = diag(M00) + first2 + last2.
+// One workgroup; thread f owns feature f (F <= 1024 per pass), at most 2 lag frames per segment.
+template <typename T>
+__global__ __launch_bounds__(256) void moments_from_lagged_kernel(const T* __restrict__ x, int F, int64_t ld,
+                                                                  EdgeSegs sg, const double* __restrict__ shift,
+                                                                  const double* __restrict__ mom,
+                                                                  double* __restrict__ sums) {
+    double frames = 0.0;
+    for (int q = 0; q < sg.n; ++q) frames += (double)(sg.stop[q] - sg.start[q]);
+    for (int f = threadIdx.x; f < F; f += blockDim.x) {
+        const double sh = shift[f];
+        double e1 = 0.0, e2 = 0.0;
+        for (int q = 0; q < sg.n; ++q) {
+            const int64_t s = sg.start[q], e = sg.stop[q];
+            const int64_t head = min<int64_t>(s + sg.lag, e), tail = max<int64_t>(e - sg.lag, s);
+            const int n_head = (int)(head - s), n_edge = n_head + (int)(e - tail);
+#pragma unroll 8
+            for (int q2 = 0; q2 < n_edge; ++q2) {   // independent loads: several rows in flight per thread
+                const int64_t t = q2 < n_head ? s + q2 : tail + (q2 - n_head);
+                const double z = (double)x[t * ld + f] - sh;
+                e1 += z;
+                e2 = fma(z, z, e2);
+            }
+        }
+        const double sx = mom[(size_t)2 * F * F + f], sy = mom[(size_t)2 * F * F + F + f];
+        sums[f] = frames;
+        sums[F + f] = 0.5 * (sx + sy + e1);
+        sums[2 * F + f] = 0.5 * (mom[(size_t)f * F + f] + e2);
+    }
+}
+
+}  // namespace
+
 extern "C" {
 
 msm_status msm_lagged_moments(msm_ctx* ctx, const void* d_x, msm_dtype dtype, int64_t n, int F, int64_t ld,
@@ -608,6 +653,36 @@ msm_status msm_lagged_moments(msm_ctx* ctx, const void* d_x, msm_dtype dtype, in
     if (dtype == MSM_F32)
         return dispatch_cov<float>(ctx, (const float*)d_x, F, ld, ft, d_shift, assume_finite != 0, d_moments);
     return dispatch_cov<double>(ctx, (const double*)d_x, F, ld, ft, d_shift, assume_finite != 0, d_moments);
+}
+
+msm_status msm_moments_from_lagged(msm_ctx* ctx, const void* d_x, msm_dtype dtype, int64_t n, int F, int64_t ld,
+                                   const int64_t* h_seg_start, const int64_t* h_seg_stop, int n_seg, int lag,
+                                   const double* d_shift, const double* d_moments, double* d_sums) {
+    if (!ctx) return MSM_ERR_INVALID;
+    MSM_REQUIRE(ctx, n >= 0 && F >= 1 && ld >= F && lag >= 1, "msm_moments_from_lagged: bad shape / lag");
+    MSM_REQUIRE(ctx, dtype == MSM_F32 || dtype == MSM_F64, "msm_moments_from_lagged: bad dtype");
+    MSM_REQUIRE(ctx, d_shift && d_moments && d_sums && (d_x || n == 0), "msm_moments_from_lagged: NULL pointer");
+    MSM_REQUIRE(ctx, n_seg >= 0 && n_seg <= MSM_SEG_INLINE && (n_seg == 0 || (h_seg_start && h_seg_stop)),
+                "msm_moments_from_lagged: at most %d segments per call", MSM_SEG_INLINE);
+    EdgeSegs sg;
+    sg.n = 0;
+    sg.lag = lag;
+    if (n_seg == 0) {
+        if (n > 0) { sg.start[0] = 0; sg.stop[0] = n; sg.n = 1; }
+    } else {
+        for (int q = 0; q < n_seg; ++q) {
+            const int64_t a = std::max<int64_t>(0, h_seg_start[q]), b = std::min<int64_t>(n, h_seg_stop[q]);
+            if (b > a) { sg.start[sg.n] = a; sg.stop[sg.n] = b; ++sg.n; }
+        }
+    }
+    if (dtype == MSM_F32)
+        hipLaunchKernelGGL(moments_from_lagged_kernel<float>, dim3(1), dim3(256), 0, ctx->stream, (const float*)d_x, F, ld,
+                           sg, d_shift, d_moments, d_sums);
+    else
+        hipLaunchKernelGGL(moments_from_lagged_kernel<double>, dim3(1), dim3(256), 0, ctx->stream, (const double*)d_x, F,
+                           ld, sg, d_shift, d_moments, d_sums);
+    MSM_CHECK_LAUNCH(ctx);
+    return MSM_OK;
 }
 
 }  // extern "C"

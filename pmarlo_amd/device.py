@@ -367,6 +367,19 @@ class Engine:
                                      out.ptr), self.handle)
         return out
 
+    def moments_from_lagged(self, x: DeviceArray, lag: int, shift: DeviceArray, moments: DeviceArray, *, starts=None,
+                            stops=None, out: DeviceArray | None = None) -> DeviceArray:
+        """[cnt | S1 | S2] over all frames from lagged moments of the same shift (finite data only)."""
+        n, F = x.shape
+        if starts is None:
+            starts, stops = segments_to_bounds(None, n)
+        starts, stops = self._seg_ptrs(starts, stops)
+        out = out if out is not None else self.empty((3 * F,), np.float64)
+        check(lib.msm_moments_from_lagged(self.handle, x.ptr, _dtype_code(x.dtype), n, F, F, starts.ctypes.data,
+                                          stops.ctypes.data, len(starts), int(lag), shift.ptr, moments.ptr, out.ptr),
+              self.handle)
+        return out
+
     def tica_solve(self, moments: DeviceArray, F: int, *, scale: DeviceArray | None = None,
                    epsilon: float = 1e-6, kinetic_map: bool = True):
         """-> (eigvals [F], coeffs [F,F], mean [F], rank int32[1]) on the device."""

@@ -169,21 +169,22 @@ class ShardedMSM:
         eng, cfg, b, comm = self.eng, self.cfg, self.buf, self.comm
         multi = comm is not None and (comm.world > 1 or self.always_exchange)
         F, d, k = cfg.n_features, cfg.tica_dim, cfg.k
-        # 1. standardisation moments
-        eng.column_moments_partial(self.x, shift=b["shift"], sums=b["mom_sums"])
+        # 1. time-lagged raw moments about the shared shift (fp64 MFMA): the only pass over X before the
+        #    projection -- the standardisation sums follow from them and 2 * lag edge frames
+        eng.lagged_moments(self.x, cfg.lag, b["shift"], assume_finite=True, out=b["lagged"])
+        eng.moments_from_lagged(self.x, cfg.lag, b["shift"], b["lagged"], out=b["mom_sums"])
         if multi:
+            comm.allreduce_sum("lagged")
             comm.allreduce_sum("mom_sums")
         eng.standardise_params(b["mom_sums"], b["shift"], F, float(self.n_total), True,
                                out=(self.mean, self.scale, self.inv_scale))
-        # 2. time-lagged covariance (fp64 MFMA) + TICA solve
-        eng.lagged_moments(self.x, cfg.lag, self.mean, assume_finite=True, out=b["lagged"])
-        if multi:
-            comm.allreduce_sum("lagged")
+        # 2. TICA solve
         check(lib.msm_tica_solve(eng.handle, b["lagged"].ptr, self.scale.ptr, F, 1e-6, 1, self.eig.ptr, self.W.ptr,
                                  self.m2.ptr, self.rank_d.ptr), eng.handle)
         # 3. projection
         # max |Y| (the fixed-point scale of the Lloyd sums needs it) falls out of the same pass
-        eng.project(self.x, self.mean, self.inv_scale, self.W, d, mean2=self.m2, out=self.Y,
+        # (x - shift) / sigma - m2: m2 is the symmetric mean about the SAME shift the moments used
+        eng.project(self.x, b["shift"], self.inv_scale, self.W, d, mean2=self.m2, out=self.Y,
                     absmax=b["fit_state"].view((1,), offset_elems=2))
         # 4. k-means: fixed number of Lloyd iterations over all frames
         check(lib.msm_kmeans_fit_begin(eng.handle, self.Y.ptr, 1, cfg.n_frames, d, d, None, None, k, cfg.seed, 1,

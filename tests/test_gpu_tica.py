@@ -260,3 +260,27 @@ def test_tica_pipeline_c5_feature_count(engine):
     for c in range(3):  # the resolved slow modes; the noise modes are near-degenerate at this N
         s = np.sign(np.dot(Y[:, c], Yo[:, c])) or 1.0
         np.testing.assert_allclose(s * Y[:, c], Yo[:, c], atol=1e-7 * max(1.0, np.abs(Yo[:, c]).max()))
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_moments_from_lagged_equals_the_separate_pass(engine, dtype):
+    """msm_moments_from_lagged: the standardisation sums recovered from the lagged moments plus the edge
+    frames equal msm_column_moments_partial's (same shift) to rounding, for several segments including
+    ones shorter than the lag (no pairs at all) and exactly lag + 1 frames."""
+    rng = np.random.default_rng(11)
+    n, F, lag = 40_000, 24, 7
+    X = (rng.normal(size=(n, F)) * rng.uniform(0.2, 5.0, size=F) + rng.normal(size=F) * 10).astype(dtype)
+    xd = engine.to_device(X)
+    for segs in (None, [(0, 15_000), (15_000, 15_005), (15_010, 15_018), (20_000, 40_000)], [(3, 3 + lag)]):
+        starts = stops = None
+        if segs is not None:
+            starts = np.asarray([a for a, _ in segs], np.int64)
+            stops = np.asarray([b for _, b in segs], np.int64)
+        rows = np.concatenate([X[a:b] for a, b in (segs or [(0, n)])]).astype(np.float64)
+        shift = engine.to_device(rows[0].copy())
+        mom = engine.lagged_moments(xd, lag, shift, starts=starts, stops=stops, assume_finite=True)
+        got = engine.moments_from_lagged(xd, lag, shift, mom, starts=starts, stops=stops).to_host()
+        z = rows - rows[0]
+        np.testing.assert_array_equal(got[:F], float(rows.shape[0]))
+        np.testing.assert_allclose(got[F:2 * F], z.sum(0), rtol=1e-11, atol=1e-9)
+        np.testing.assert_allclose(got[2 * F:], (z * z).sum(0), rtol=1e-12)
