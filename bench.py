@@ -189,7 +189,7 @@ def main() -> None:
                        "parallelism": f"shards{world}",
                        "exchange": ("rccl" if os.environ.get("BENCH_BACKEND", "nccl") == "nccl" else "gloo") if multi
                        else None},
-            "roofline": {"kernel": "kmeans_mfma_kernel<double,3,2,1024,true,true> (assign + accumulate)", "bound": "mfma",
+            "roofline": {"kernel": "kmeans_mfma_kernel<double,3,2,1024,true,true,false> (assign + accumulate)", "bound": "mfma",
                          "achieved": achieved_tf, "peak": FP64_MFMA_PEAK_TF, "unit": "TFLOP/s",
                          "frac": achieved_tf / FP64_MFMA_PEAK_TF,
                          "traffic": KMEANS_ACCUM_TRAFFIC_BYTES if n == N_FRAMES else None,
