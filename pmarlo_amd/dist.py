@@ -5,8 +5,8 @@ so the big arrays (features, projected coordinates, labels) never leave their GP
 exchanged, by plain summation over RCCL/xGMI (``torch.distributed``, backend "nccl"):
 
   exchange                      payload                         when
-  standardisation sums          3F f64                          once
-  lagged moments                2F^2 + 2F + 1 f64               once
+  lagged moments + the          2F^2 + 2F + 1 + 3F f64          once (one buffer, one collective)
+    standardisation sums
   k-means fixed-point scale     1 f64 (MIN) + centres bcast     once
   k-means member sums / counts  k*d + k int64 (exact)           per Lloyd iteration
   transition counts             k^2 int64 (exact)               once
@@ -25,7 +25,8 @@ import numpy as np
 
 from .device import DeviceArray, Engine
 
-__all__ = ["Comm", "ShardedMSM", "ShardConfig"]
+__all__ = ["Comm", "ShardedMSM", "ShardConfig", "exchange_shapes", "exchange_aliases", "TorchComm",
+           "torch_exchange_buffers"]
 
 
 class Comm:
@@ -115,8 +116,8 @@ def exchange_shapes(cfg: ShardConfig) -> dict[str, tuple[tuple[int, ...], str]]:
     F, d, k = cfg.n_features, cfg.tica_dim, cfg.k
     return {
         "shift": ((F,), "float64"),
-        "mom_sums": ((3 * F,), "float64"),
-        "lagged": ((2 * F * F + 2 * F + 1,), "float64"),
+        # [lagged moments 2F^2 + 2F + 1 | standardisation sums 3F]: both are raw sums about the shared shift
+        "moments": ((2 * F * F + 2 * F + 1 + 3 * F,), "float64"),
         "fit_state": ((8,), "float64"),
         "centers": ((k, d), "float64"),
         "km_acc": ((k * d + k,), "int64"),
@@ -141,6 +142,9 @@ class ShardedMSM:
         self.buf = shared if shared is not None else {
             nm: eng.zeros(shape, np.dtype(dt)) for nm, (shape, dt) in exchange_shapes(cfg).items()}
         b = self.buf
+        for name, (parent, first, length) in exchange_aliases(cfg).items():
+            if name not in b:
+                b[name] = b[parent].view((length,), offset_elems=first)
         self.mean, self.scale, self.inv_scale = (eng.empty((F,), np.float64) for _ in range(3))
         self.eig = eng.empty((F,), np.float64)
         self.W = eng.empty((F, F), np.float64)
@@ -174,8 +178,7 @@ class ShardedMSM:
         eng.lagged_moments(self.x, cfg.lag, b["shift"], assume_finite=True, out=b["lagged"])
         eng.moments_from_lagged(self.x, cfg.lag, b["shift"], b["lagged"], out=b["mom_sums"])
         if multi:
-            comm.allreduce_sum("lagged")
-            comm.allreduce_sum("mom_sums")
+            comm.allreduce_sum("moments")
         eng.standardise_params(b["mom_sums"], b["shift"], F, float(self.n_total), True,
                                out=(self.mean, self.scale, self.inv_scale))
         # 2. TICA solve
@@ -217,10 +220,18 @@ class ShardedMSM:
                                         self.rowsum.ptr, self.diag.ptr), eng.handle)
 
 
+def exchange_aliases(cfg: ShardConfig) -> dict[str, tuple[str, int, int]]:
+    """name -> (parent buffer, first element, length) of the named parts of exchange buffers."""
+    F = cfg.n_features
+    L = 2 * F * F + 2 * F + 1
+    return {"lagged": ("moments", 0, L), "mom_sums": ("moments", L, 3 * F),
+            "fit_scale": ("fit_state", 0, 1), "fit_inv_scale": ("fit_state", 1, 1)}
+
+
 def torch_exchange_buffers(engine: Engine, cfg: ShardConfig, device) -> tuple[dict, dict]:
     """Allocate the exchange buffers as torch tensors on `device` (so torch.distributed can
-    reduce them) and return (tensors, DeviceArray views for the engine).  The two extra
-    entries "fit_scale" / "fit_inv_scale" alias elements 0 / 1 of "fit_state"."""
+    reduce them) and return (tensors, DeviceArray views for the engine).  The entries of
+    exchange_aliases() ("lagged", "mom_sums", "fit_scale", "fit_inv_scale") alias parts of their parents."""
     import torch
 
     tensors, views = {}, {}
@@ -228,6 +239,7 @@ def torch_exchange_buffers(engine: Engine, cfg: ShardConfig, device) -> tuple[di
         t = torch.zeros(shape, dtype=getattr(torch, dt), device=device)
         tensors[name] = t
         views[name] = engine.wrap(t.data_ptr(), shape, np.dtype(dt))
-    tensors["fit_scale"] = tensors["fit_state"][0:1]
-    tensors["fit_inv_scale"] = tensors["fit_state"][1:2]
+    for name, (parent, first, length) in exchange_aliases(cfg).items():
+        tensors[name] = tensors[parent][first:first + length]
+        views[name] = views[parent].view((length,), offset_elems=first)
     return tensors, views

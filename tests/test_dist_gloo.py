@@ -26,15 +26,15 @@ def _worker(rank: int, world: int, port: int, out_dir: str) -> None:
     import torch.distributed as dist
 
     from oracle import cport, npport
-    from pmarlo_amd.dist import ShardConfig, TorchComm, exchange_shapes
+    from pmarlo_amd.dist import ShardConfig, TorchComm, exchange_aliases, exchange_shapes
     from tests import _gen
 
     dist.init_process_group("gloo", rank=rank, world_size=world)
     n, F, d, k, lag = 6000, 8, 3, 12, 5
     cfg = ShardConfig(n_frames=n, n_features=F, tica_dim=d, k=k, lag=lag, n_total=n * world)
     tensors = {nm: torch.zeros(shape, dtype=getattr(torch, dt)) for nm, (shape, dt) in exchange_shapes(cfg).items()}
-    tensors["fit_scale"] = tensors["fit_state"][0:1]
-    tensors["fit_inv_scale"] = tensors["fit_state"][1:2]
+    for name, (parent, first, length) in exchange_aliases(cfg).items():
+        tensors[name] = tensors[parent][first:first + length]
     comm = TorchComm(tensors)
     assert comm.world == world and comm.rank == rank
 
@@ -45,16 +45,16 @@ def _worker(rank: int, world: int, port: int, out_dir: str) -> None:
     comm.broadcast("shift", 0)
     shift = tensors["shift"].numpy().copy()
     dlt = X - shift
+    # the step's protocol: lagged moments and standardisation sums about the shared shift, ONE collective
     tensors["mom_sums"].copy_(torch.from_numpy(np.concatenate([np.full(F, float(n)), dlt.sum(0), (dlt ** 2).sum(0)])))
-    comm.allreduce_sum("mom_sums")
+    m = npport.lagged_moments([dlt], lag)
+    tensors["lagged"].copy_(torch.from_numpy(np.concatenate([m["Mxx"].ravel(), m["Mxy_half"].ravel(), m["sx"], m["sy"],
+                                                              [float(m["T"])]])))
+    comm.allreduce_sum("moments")
     s = tensors["mom_sums"].numpy()
     cnt, s1, s2 = s[:F], s[F:2 * F], s[2 * F:]
     mean = shift + s1 / cnt
     sigma = np.sqrt((s2 - s1 * s1 / cnt) / (n * world))
-    m = npport.lagged_moments([X - mean], lag)
-    tensors["lagged"].copy_(torch.from_numpy(np.concatenate([m["Mxx"].ravel(), m["Mxy_half"].ravel(), m["sx"], m["sy"],
-                                                              [float(m["T"])]])))
-    comm.allreduce_sum("lagged")
     # k-means exchange: scale MIN, centres broadcast, int64 sums
     Y = (X - mean) / sigma
     Y = Y[:, :d].copy()
@@ -103,7 +103,7 @@ def test_two_rank_exchange_equals_single_shard(tmp_path):
     np.testing.assert_allclose(g["mean"], Xall.mean(0), rtol=1e-12)
     np.testing.assert_allclose(g["sigma"], Xall.std(0), rtol=1e-12)
     # lagged moments: per-shard pairs only (no pair crosses the shard boundary)
-    ref = npport.lagged_moments([X - g["mean"] for X in Xs], lag)
+    ref = npport.lagged_moments([X - g["shift"] for X in Xs], lag)
     lagged = g["lagged"]
     np.testing.assert_allclose(lagged[:F * F].reshape(F, F), ref["Mxx"], rtol=1e-12, atol=1e-9)
     np.testing.assert_allclose(lagged[F * F:2 * F * F].reshape(F, F), ref["Mxy_half"], rtol=1e-12, atol=1e-9)
@@ -129,7 +129,6 @@ def test_exchange_payload_sizes_match_survey():
 
     sh = exchange_shapes(ShardConfig(n_frames=1_000_000, n_features=64, tica_dim=10, k=500, lag=10))
     nbytes = {k: int(np.prod(s)) * 8 for k, (s, _) in sh.items()}
-    assert nbytes["mom_sums"] == 3 * 64 * 8                     # ~1.5 KB
-    assert nbytes["lagged"] == (2 * 64 * 64 + 2 * 64 + 1) * 8   # ~66 KB
+    assert nbytes["moments"] == (2 * 64 * 64 + 2 * 64 + 1 + 3 * 64) * 8   # ~68 KB: lagged moments + the sums
     assert nbytes["km_acc"] == (500 * 10 + 500) * 8             # 44 KB per Lloyd iteration
     assert nbytes["counts"] == (500 * 500 + 1) * 8              # 2 MB (+ the pair count)
