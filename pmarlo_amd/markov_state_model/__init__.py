@@ -14,6 +14,7 @@ from .its import (  # noqa: F401
 )
 from .pcca import canonicalize_macro_labels, pcca_like_macrostates, pcca_memberships  # noqa: F401
 from .reduction import pca_reduce, reduce_features, tica_reduce, vamp_reduce  # noqa: F401
-from .tpt import (ReactiveFlux, compute_committor, compute_macro_mfpt, compute_macro_populations,  # noqa: F401
-                  lump_micro_to_macro_T, reactive_flux)
+from .tpt import (ReactiveFlux, coarse_grain_flux, compute_committor, compute_macro_mfpt,  # noqa: F401
+                  compute_macro_populations, find_bottleneck_states, identify_transition_state_ensemble,
+                  lump_micro_to_macro_T, pathway_decomposition, reactive_flux)
 from .results import ConnectedCountResult, ITSResult, MSMEstimate  # noqa: F401

@@ -4,8 +4,10 @@ Mirrors the numerics behind pmarlo.markov_state_model._tpt.TPTMixin (S/markov_st
 _tpt.py:39-160 reactive_flux / compute_committor, :255-347 net / gross flux, rate, mfpt -- all
 delegated to deeptime 0.4.5 in the reference; the published dense algorithm is restated, parity
 unpinned) and lump_micro_to_macro_T / compute_macro_populations / compute_macro_mfpt
-(S/markov_state_model/_msm_utils.py:103-160).  Not mirrored: pathway decomposition, flux
-coarse-graining, PCCA+ itself."""
+(S/markov_state_model/_msm_utils.py:103-160), pathway_decomposition / coarse_grain_flux /
+identify_transition_state_ensemble / find_bottleneck_states (_tpt.py:162-429).  The dense solves and
+matrix products run on the device; the path search of the decomposition is a graph walk over the k x k
+net-flux matrix on the host (deeptime does the same in Python)."""
 
 from __future__ import annotations
 
@@ -16,7 +18,8 @@ import numpy as np
 from ..device import get_engine
 
 __all__ = ["ReactiveFlux", "reactive_flux", "compute_committor", "lump_micro_to_macro_T", "compute_macro_populations",
-           "compute_macro_mfpt"]
+           "compute_macro_mfpt", "pathway_decomposition", "coarse_grain_flux", "identify_transition_state_ensemble",
+           "find_bottleneck_states"]
 
 
 @dataclass
@@ -134,3 +137,131 @@ def compute_macro_mfpt(T_macro: np.ndarray) -> np.ndarray:
         M[:, j] = np.nan
         M[j, j] = 0.0
     return M
+
+
+def _widest_path(F: np.ndarray, src: int, dst: int):
+    """Path src -> dst that maximises its smallest edge (max-min Dijkstra; ties: lower state index first).
+    Returns (path, capacity) or (None, 0.0) when dst cannot be reached over positive edges."""
+    import heapq
+
+    n = F.shape[0]
+    width = np.zeros(n)
+    width[src] = np.inf
+    prev = np.full(n, -1, dtype=int)
+    done = np.zeros(n, dtype=bool)
+    heap = [(-np.inf, src)]
+    while heap:
+        w, i = heapq.heappop(heap)
+        if done[i]:
+            continue
+        done[i] = True
+        if i == dst:
+            break
+        row = F[i]
+        for j in np.flatnonzero(row > 0):
+            cand = min(-w, row[j])
+            if not done[j] and cand > width[j]:
+                width[j] = cand
+                prev[j] = i
+                heapq.heappush(heap, (-cand, int(j)))
+    if not done[dst] or width[dst] <= 0:
+        return None, 0.0
+    path = [dst]
+    while path[-1] != src:
+        path.append(int(prev[path[-1]]))
+    return path[::-1], float(width[dst])
+
+
+def pathway_decomposition(transition_matrix, stationary_distribution, source_states, sink_states, fraction: float = 0.99,
+                          maxiter: int = 10000):
+    """Dominant reactive pathways A -> B: repeatedly take the path of the largest bottleneck through the
+    net flux and remove its capacity, until `fraction` of the total flux is collected or `maxiter` paths
+    were taken (TPTMixin.pathway_decomposition, S/markov_state_model/_tpt.py:162-211; deeptime's
+    ReactiveFlux.pathways restated from Metzner, Schuette, Vanden-Eijnden, MMS 7 (2009)).
+    Returns (paths as lists of state indices, capacities)."""
+    if not 0.0 < fraction <= 1.0:
+        raise ValueError("fraction must be in (0, 1]")
+    flux = reactive_flux(transition_matrix, stationary_distribution, source_states, sink_states)
+    n = flux.net_flux.shape[0]
+    A, B = flux.source_states, flux.sink_states
+    # virtual end states n (feeds A) and n + 1 (drains B) make the search single-source / single-sink
+    G = np.zeros((n + 2, n + 2))
+    G[:n, :n] = flux.net_flux
+    out_A = flux.net_flux[A].sum(axis=1)
+    in_B = flux.net_flux[:, B].sum(axis=0)
+    G[n, A] = out_A
+    G[B, n + 1] = in_B
+    total = float(out_A.sum())
+    paths, caps, got = [], [], 0.0
+    while len(paths) < int(maxiter) and total > 0 and got < fraction * total * (1.0 - 1e-14):
+        path, cap = _widest_path(G, n, n + 1)
+        if path is None or cap <= 1e-14 * total:
+            break
+        for a, b in zip(path[:-1], path[1:]):
+            G[a, b] = max(0.0, G[a, b] - cap)
+        paths.append([int(v) for v in path[1:-1]])
+        caps.append(cap)
+        got += cap
+    return paths, np.asarray(caps, dtype=float)
+
+
+def coarse_grain_flux(transition_matrix, stationary_distribution, source_states, sink_states, sets):
+    """Reactive flux between sets of states (TPTMixin.coarse_grain_flux, _tpt.py:213-253; deeptime's
+    ReactiveFlux.coarse_grain restated): every user set is split into its parts inside the source, the
+    intermediates and the sink (states no set names form one more set), ordered source parts, intermediate
+    parts, sink parts; gross flux is summed over the blocks (two matrix products on the device), the net
+    flux is its antisymmetric positive part, committors are pi-weighted means.
+    Returns (list of sets, ReactiveFlux over the sets)."""
+    flux = reactive_flux(transition_matrix, stationary_distribution, source_states, sink_states)
+    n = flux.gross_flux.shape[0]
+    A, B = set(flux.source_states), set(flux.sink_states)
+    user = [set(int(v) for v in s) for s in sets]
+    for s in user:
+        if s and (min(s) < 0 or max(s) >= n):
+            raise ValueError("set member out of range")
+    named = set().union(*user) if user else set()
+    if len(named) != sum(len(s) for s in user):
+        raise ValueError("sets must be disjoint")
+    rest = set(range(n)) - named
+    if rest:
+        user.append(rest)
+    inter = set(range(n)) - A - B
+    parts_A = [s & A for s in user if s & A]
+    parts_I = [s & inter for s in user if s & inter]
+    parts_B = [s & B for s in user if s & B]
+    tpt_sets = parts_A + parts_I + parts_B
+    m = len(tpt_sets)
+    S = np.zeros((n, m))
+    for q, s in enumerate(tpt_sets):
+        S[sorted(s), q] = 1.0
+    eng = get_engine()
+    Sd = eng.to_device(S)
+    gross = eng.gemm(eng.to_device(np.ascontiguousarray(S.T)), eng.gemm(eng.to_device(flux.gross_flux), Sd)).to_host()
+    np.fill_diagonal(gross, 0.0)
+    net = np.maximum(gross - gross.T, 0.0)
+    pi = flux.stationary_distribution
+    pops = S.T @ pi
+    with np.errstate(divide="ignore", invalid="ignore"):
+        qp = np.where(pops > 0, (S.T @ (pi * flux.forward_committor)) / pops, 0.0)
+        qm = np.where(pops > 0, (S.T @ (pi * flux.backward_committor)) / pops, 0.0)
+    a_idx = list(range(len(parts_A)))
+    b_idx = list(range(len(parts_A) + len(parts_I), m))
+    total = float(net[a_idx].sum())
+    z = float(np.sum(pops * qm))
+    rate = total / z if z > 0 else float("nan")
+    cg = ReactiveFlux(a_idx, b_idx, qp, qm, gross, net, total, rate, 1.0 / rate if rate > 0 else float("inf"), pops)
+    return tpt_sets, cg
+
+
+def identify_transition_state_ensemble(transition_matrix, source_states, sink_states, tolerance: float = 0.1) -> np.ndarray:
+    """States whose forward committor lies within `tolerance` of one half (_tpt.py:349-385)."""
+    q = compute_committor(transition_matrix, source_states, sink_states, forward=True)
+    return np.where((q >= 0.5 - tolerance) & (q <= 0.5 + tolerance))[0]
+
+
+def find_bottleneck_states(transition_matrix, stationary_distribution, source_states, sink_states, top_n: int = 10) -> np.ndarray:
+    """The top_n states by reactive flux passing through them, (row sum + column sum) / 2 of the gross flux,
+    descending (_tpt.py:387-426)."""
+    flux = reactive_flux(transition_matrix, stationary_distribution, source_states, sink_states)
+    through = 0.5 * (flux.gross_flux.sum(axis=1) + flux.gross_flux.sum(axis=0))
+    return np.argsort(through)[::-1][:int(top_n)]

@@ -100,3 +100,80 @@ def test_lumping_and_macro_mfpt(n, n_macro):
     # two-state analytic: mfpt 0 -> 1 = 1 / p01
     M2 = compute_macro_mfpt(np.array([[0.9, 0.1], [0.25, 0.75]]))
     np.testing.assert_allclose(M2, [[0.0, 10.0], [4.0, 0.0]], rtol=1e-12)
+
+
+def _two_route_network():
+    """0 -> {1 -> 2 | 3} -> 4: a strong route over 1, 2 and a weak one over 3 (symmetric weights: reversible)."""
+    W = np.zeros((5, 5))
+    for i, j, w in ((0, 1, 4.0), (1, 2, 3.0), (2, 4, 4.0), (0, 3, 1.0), (3, 4, 1.0), (1, 3, 0.2)):
+        W[i, j] = W[j, i] = w
+    W += np.diag([6.0, 5.0, 5.0, 4.0, 6.0])
+    T = W / W.sum(1, keepdims=True)
+    pi = W.sum(1) / W.sum()
+    return T, pi
+
+
+def test_pathway_decomposition():
+    from pmarlo_amd.markov_state_model import pathway_decomposition, reactive_flux
+
+    T, pi = _two_route_network()
+    flux = reactive_flux(T, pi, [0], [4])
+    paths, caps = pathway_decomposition(T, pi, [0], [4], fraction=1.0)
+    assert paths[0] == [0, 1, 2, 4] and paths[1] == [0, 3, 4]               # widest bottleneck first
+    assert all(p[0] == 0 and p[-1] == 4 for p in paths)
+    assert np.all(np.diff(caps) <= 1e-15)                                     # capacities never grow
+    np.testing.assert_allclose(caps.sum(), flux.total_flux, rtol=1e-12)       # the paths carry the whole flux
+    for p, c in zip(paths, caps):                                             # no path exceeds any of its edges
+        assert all(flux.net_flux[a, b] >= c * (1 - 1e-12) for a, b in zip(p[:-1], p[1:]))
+    few, fc = pathway_decomposition(T, pi, [0], [4], fraction=0.5)
+    assert len(few) == 1 and fc[0] >= 0.5 * flux.total_flux
+    one, _ = pathway_decomposition(T, pi, [0], [4], fraction=1.0, maxiter=1)
+    assert len(one) == 1
+    # a larger metastable chain: conservation again, several source / sink states
+    Tm = _metastable_T(40, seed=5, reversible=True)
+    w, v = np.linalg.eig(Tm.T)
+    pim = np.real(v[:, np.argmax(np.real(w))])
+    pim /= pim.sum()
+    fm = reactive_flux(Tm, pim, [0, 1, 2], [37, 38, 39])
+    pm, cm = pathway_decomposition(Tm, pim, [0, 1, 2], [37, 38, 39], fraction=0.9)
+    assert 0.9 * fm.total_flux * (1 - 1e-12) <= cm.sum() <= fm.total_flux * (1 + 1e-12)
+    assert all(p[0] in (0, 1, 2) and p[-1] in (37, 38, 39) for p in pm)
+    with pytest.raises(ValueError):
+        pathway_decomposition(T, pi, [0], [4], fraction=0.0)
+
+
+def test_coarse_grain_flux_tse_and_bottlenecks():
+    from pmarlo_amd.markov_state_model import (coarse_grain_flux, compute_committor, find_bottleneck_states,
+                                              identify_transition_state_ensemble, reactive_flux)
+
+    T = _metastable_T(40, seed=7, reversible=True)
+    w, v = np.linalg.eig(T.T)
+    pi = np.real(v[:, np.argmax(np.real(w))])
+    pi /= pi.sum()
+    A, B = [0, 1, 2, 3], [36, 37, 38, 39]
+    flux = reactive_flux(T, pi, A, B)
+    sets = [list(range(0, 10)), list(range(10, 20)), list(range(20, 30))]      # 30..39 not named: one more set
+    tpt_sets, cg = coarse_grain_flux(T, pi, A, B, sets)
+    # source parts, intermediate parts, sink parts, in that order
+    assert tpt_sets == [set(range(0, 4)), set(range(4, 10)), set(range(10, 20)), set(range(20, 30)), set(range(30, 36)),
+                        set(range(36, 40))]
+    assert cg.source_states == [0] and cg.sink_states == [5]
+    S = np.zeros((40, 6))
+    for q, s in enumerate(tpt_sets):
+        S[sorted(s), q] = 1.0
+    want = S.T @ flux.gross_flux @ S
+    np.fill_diagonal(want, 0.0)
+    np.testing.assert_allclose(cg.gross_flux, want, rtol=1e-12, atol=1e-18)
+    np.testing.assert_allclose(cg.total_flux, flux.total_flux, rtol=1e-10)       # A and B are whole sets: conserved
+    np.testing.assert_allclose(cg.rate, flux.rate, rtol=1e-10)
+    np.testing.assert_allclose(cg.stationary_distribution, S.T @ pi, rtol=1e-13)
+    assert cg.forward_committor[0] == 0.0 and cg.forward_committor[5] == pytest.approx(1.0, abs=1e-12)
+    assert np.all((cg.forward_committor >= 0) & (cg.forward_committor <= 1 + 1e-12))
+    np.testing.assert_allclose(cg.forward_committor, (S.T @ (pi * flux.forward_committor)) / (S.T @ pi), rtol=1e-13)
+    with pytest.raises(ValueError, match="disjoint"):
+        coarse_grain_flux(T, pi, A, B, [[0, 1], [1, 2]])
+    q = compute_committor(T, A, B)
+    np.testing.assert_array_equal(identify_transition_state_ensemble(T, A, B, tolerance=0.2),
+                                  np.where((q >= 0.3) & (q <= 0.7))[0])
+    through = 0.5 * (flux.gross_flux.sum(1) + flux.gross_flux.sum(0))
+    np.testing.assert_array_equal(find_bottleneck_states(T, pi, A, B, top_n=5), np.argsort(through)[::-1][:5])
