@@ -370,10 +370,12 @@ msm_status msm_embed_full(msm_ctx* ctx, const double* d_T_active, const double* 
  *   p        subspace size (<= 32; use n_its + 1 + guard vectors)
  *   n_iter   iterations this call; init != 0 (re)starts from a seeded basis, init == 0
  *            continues from the basis left in d_workspace by the previous call
- *   d_ritz   f64 [batch][128] = {re[32] | im[32] | previous re[32] | previous im[32]},
- *            Ritz values sorted by descending magnitude
- *   d_change f64 [batch]: max relative change of the top n_watch Ritz values over the last
- *            4 iterations -- the caller relaunches with init = 0 until it is small
+ *   d_ritz   f64 [batch][128] = {re[32] | im[32] | previous call's re[32] | im[32]},
+ *            Ritz values sorted by descending magnitude (the caller keeps the buffer between calls)
+ *   d_change f64 [batch]: convergence measure of the top n_watch Ritz values -- the residual
+ *            ||T'x - theta x|| / ||x|| of every real Ritz pair, for a complex value its relative
+ *            change since the previous call (1 right after init) -- the caller relaunches with
+ *            init = 0 until it is small
  *   d_pi     f64 [batch][pi_stride] stationary distribution (sum 1), or NULL
  *   n_its>0: d_its_eig / d_its_ts f64 [batch][n_its]: the top (n_its+1) values re-sorted by
  *            descending real part, first dropped, |real part| clipped to [1e-12, 1-1e-12],

@@ -254,11 +254,18 @@ __device__ __forceinline__ void spec_gram_fast(const double* __restrict__ A, con
 }
 
 __device__ void spec_ritz(SpecShared* sh, int p, double* out_re, double* out_im) {
-    // thread 0: eigenvalues of a copy of H, sorted by descending magnitude
+    // wave 0: eigenvalues of a copy of H (lanes share the row / column updates); lane 0 sorts them by
+    // descending magnitude
+    if (threadIdx.x < 64) {
+        for (int i = threadIdx.x; i < p * p; i += 64) sh->Hw[i] = sh->H[i];
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        const int rc = small_eig::eigenvalues_wave(sh->Hw, p, p, sh->wr, sh->wi);
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        if (rc && threadIdx.x == 0) sh->status = rc;
+    }
     if (threadIdx.x == 0) {
-        for (int i = 0; i < p * p; ++i) sh->Hw[i] = sh->H[i];
-        const int rc = small_eig::eigenvalues(sh->Hw, p, p, sh->wr, sh->wi);
-        if (rc) sh->status = rc;
         for (int i = 0; i < p; ++i) {
             const double a = sh->wr[i] * sh->wr[i] + sh->wi[i] * sh->wi[i];
             int rank = 0;
@@ -341,7 +348,6 @@ __device__ unsigned long long g_spec_stamps[8];
 // mode bits
 constexpr int kStepInit = 1;     // seeded basis -> orthonormal Z (no partials involved)
 constexpr int kStepOrtho = 2;    // Z <- orth(W)
-constexpr int kStepCheck = 4;    // H = Z'W and "previous" Ritz values (needs an orthonormal Z)
 constexpr int kStepFinish = 8;   // Rayleigh-Ritz, residuals, pi, implied timescales
 
 // Z = W R^-1 for upper-triangular R (p x p in LDS): R^-1 by one wave (lane = column), then a
@@ -491,10 +497,6 @@ __global__ __launch_bounds__(kSolveThreads) void spec_step_kernel(SpecArgs ar, i
         }
     }
     SSTAMP(0);
-    if (mode & kStepCheck) {
-        spec_gram_fast(Z, W, n, p, sh.H, sh.Hw);
-        spec_ritz(&sh, p, ritz + 2 * kMaxP, ritz + 3 * kMaxP);
-    }
     if (mode & kStepOrtho) {
         spec_gram_fast(W, W, n, p, sh.G, sh.Hw);
         SSTAMP(1);
@@ -507,7 +509,11 @@ __global__ __launch_bounds__(kSolveThreads) void spec_step_kernel(SpecArgs ar, i
         if (tid == 0 && sh.status) ar.status[b] = sh.status;
         return;
     }
-    // ---- Rayleigh-Ritz on the (orthonormal) basis Z with W = T'Z
+    // ---- Rayleigh-Ritz on the (orthonormal) basis Z with W = T'Z.  The values the previous call left
+    // become the "previous" ones (complex pairs are judged by their change across calls: one small
+    // nonsymmetric eigensolve per call instead of two).
+    for (int i = tid; i < 2 * kMaxP; i += blockDim.x) ritz[2 * kMaxP + i] = ritz[i];
+    __syncthreads();
     spec_gram_fast(Z, W, n, p, sh.H, sh.Hw);
     spec_ritz(&sh, p, ritz, ritz + kMaxP);
     for (int i = p + tid; i < kMaxP; i += blockDim.x) { ritz[i] = 0.0; ritz[kMaxP + i] = 0.0; }
@@ -523,11 +529,11 @@ __global__ __launch_bounds__(kSolveThreads) void spec_step_kernel(SpecArgs ar, i
             if (th_im != 0.0) {
                 const double dr = th_re - ritz[2 * kMaxP + wv], di = th_im - ritz[3 * kMaxP + wv];
                 const double mag = sqrt(th_re * th_re + th_im * th_im);
-                const double ch = ar.check_gap > 0 ? sqrt(dr * dr + di * di) / fmax(mag, 1e-300) : 1.0;
+                const double ch = ar.init ? 1.0 : sqrt(dr * dr + di * di) / fmax(mag, 1e-300);   // no history yet
                 worst = fmax(worst, ch);
                 continue;
             }
-            if (tid == 0) small_eig::eigenvector(sh.H, p, p, th_re, sh.y, sh.Hw);
+            if (tid < 64) small_eig::eigenvector_wave(sh.H, p, p, th_re, sh.y, sh.Hw);
             __syncthreads();
             double rn = 0.0, xn = 0.0;
             for (int i = tid; i < n; i += blockDim.x) {
@@ -549,7 +555,7 @@ __global__ __launch_bounds__(kSolveThreads) void spec_step_kernel(SpecArgs ar, i
     __syncthreads();
     // stationary distribution: Ritz vector of the eigenvalue nearest 1
     if (ar.pi) {
-        if (tid == 0) {
+        if (tid < 64) {
             int best = 0;
             double bd = 1e300;
             for (int i = 0; i < p; ++i) {
@@ -557,7 +563,7 @@ __global__ __launch_bounds__(kSolveThreads) void spec_step_kernel(SpecArgs ar, i
                 const double dd = dr * dr + di * di;
                 if (dd < bd) { bd = dd; best = i; }
             }
-            small_eig::eigenvector(sh.H, p, p, sh.wr[best], sh.y, sh.Hw);
+            small_eig::eigenvector_wave(sh.H, p, p, sh.wr[best], sh.y, sh.Hw);
         }
         __syncthreads();
         double* pi = ar.pi + (size_t)b * ar.pi_stride;
@@ -595,7 +601,7 @@ __global__ __launch_bounds__(kSolveThreads) void spec_step_kernel(SpecArgs ar, i
                 continue;
             }
             __syncthreads();
-            if (tid == 0) small_eig::eigenvector(sh.H, p, p, sh.wr[id], sh.y, sh.Hw);
+            if (tid < 64) small_eig::eigenvector_wave(sh.H, p, p, sh.wr[id], sh.y, sh.Hw);
             __syncthreads();
             double nn = 0.0, big = 0.0;
             for (int i = tid; i < n; i += blockDim.x) {
@@ -735,10 +741,7 @@ msm_status msm_spectrum(msm_ctx* ctx, const double* d_T, int64_t t_stride, int l
     // Cholesky-QR squares the condition number of W, and a metastable T damps the fast directions
     // by lambda^q -- already q = 6 un-orthogonalised applications broke the factorisation.
     constexpr int kOrthoEvery = 1;
-    int check_it = -1;
-    for (int it = 0; it + 4 < n_iter || (it + 1 < n_iter && check_it < 0); ++it)
-        if (it == 0 || (it % kOrthoEvery) == 0) check_it = it;  // basis orthonormal when step `it` starts
-    ar.check_gap = check_it >= 0 ? n_iter - check_it : 0;
+    ar.check_gap = n_iter;
     auto apply = [&](const double* zin) {
         const dim3 grid((unsigned)((n_max + 255) / 256), kSpecSplits, (unsigned)batch);
         if (p <= 8) hipLaunchKernelGGL(spec_apply_kernel<8>, grid, dim3(kApplyThreads), 0, ctx->stream, ar, zin, partial, part_stride);
@@ -769,7 +772,7 @@ msm_status msm_spectrum(msm_ctx* ctx, const double* d_T, int64_t t_stride, int l
     for (int it = 0; it < n_iter; ++it) {
         apply(cur);
         const bool ortho = (it % kOrthoEvery) == kOrthoEvery - 1 || it == n_iter - 1;
-        const int mode = (it == check_it ? kStepCheck : 0) | (ortho ? kStepOrtho : 0);
+        const int mode = ortho ? kStepOrtho : 0;
         step(mode, cur, other);   // sum -> other; ortho: orth(other) -> cur
         if (!ortho) std::swap(cur, other);
         MSM_CHECK_LAUNCH(ctx);
