@@ -8,8 +8,8 @@ Workload (BASELINE.json metric "... 1Mx64 synth"): per GPU one synthetic shard o
 1,000,000 frames x 64 float32 features (AR(1)-latent generator of the reference's
 tests/perf/test_tica_perf.py:65-81, vectorised; seed 1000 + rank), already resident in
 HBM when the timed region starts.  One step = one pass of the whole path over the shard:
-standardisation moments -> fp64-MFMA lagged covariance -> on-device TICA solve (dim 10)
--> projection -> k-means (k = 500, seeded init + 10 full-batch Lloyd iterations, fp64-MFMA
+fp64-MFMA lagged covariance (the standardisation sums come out of it) -> on-device TICA solve
+(dim 10) -> projection (with max |Y| for the fixed-point scale) -> k-means (k = 500, seeded init + 10 full-batch Lloyd iterations, fp64-MFMA
 assignment) -> final assignment -> lag-10 transition counts -> row-normalised T.
 Weak scaling: every rank holds its own shard; only the small moment / count / centre
 buffers are all-reduced (pmarlo_amd/dist.py).
