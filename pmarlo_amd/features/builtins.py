@@ -11,8 +11,8 @@ import numpy as np
 from ..device import get_engine
 from .base import register_feature
 
-__all__ = ["PhiPsiFeature", "DistanceFeature", "AngleFeature", "DihedralFeature", "RadiusOfGyrationFeature",
-           "DistancePairFeature", "ContactsPairFeature"]
+__all__ = ["PhiPsiFeature", "Chi1Feature", "DistanceFeature", "AngleFeature", "DihedralFeature",
+           "RadiusOfGyrationFeature", "DistancePairFeature", "ContactsPairFeature"]
 
 
 def _device_features(traj, **kw) -> np.ndarray:
@@ -39,6 +39,30 @@ class PhiPsiFeature:
         self.labels = ([f"phi:res{int(traj.topology.res_index[q[1]])}" for q in phi_idx]
                        + [f"psi:res{int(traj.topology.res_index[q[2]])}" for q in psi_idx])
         self._periodic = np.ones((X.shape[1],), dtype=bool)
+        return X
+
+    def is_periodic(self) -> np.ndarray:
+        return np.empty((0,), dtype=bool) if self._periodic is None else self._periodic
+
+
+class Chi1Feature:
+    """Side-chain chi1 of every residue with a gamma atom, wrapped to (-pi, pi], periodic
+    (S/features/builtins.py:138-168; mdtraj.compute_chi1's atom patterns)."""
+
+    name = "chi1"
+
+    def __init__(self) -> None:
+        self._periodic: np.ndarray | None = None
+        self.labels: list[str] | None = None
+
+    def compute(self, traj, **kwargs) -> np.ndarray:
+        quads = traj.topology.chi1_indices()
+        if len(quads) == 0:
+            self.labels = []
+            return np.zeros((traj.n_frames, 0), dtype=float)
+        X = _device_features(traj, quads=quads)
+        self._periodic = np.ones((X.shape[1],), dtype=bool)
+        self.labels = [f"chi1:res{int(traj.topology.res_index[q[1]])}" for q in quads]
         return X
 
     def is_periodic(self) -> np.ndarray:
@@ -142,6 +166,6 @@ class ContactsPairFeature(_PairKwFeature):
         return out.to_host().astype(float)
 
 
-for _cls in (PhiPsiFeature, DistanceFeature, AngleFeature, DihedralFeature, RadiusOfGyrationFeature,
+for _cls in (PhiPsiFeature, Chi1Feature, DistanceFeature, AngleFeature, DihedralFeature, RadiusOfGyrationFeature,
              DistancePairFeature, ContactsPairFeature):
     register_feature(_cls())

@@ -14,11 +14,14 @@ _SUPPORTED = ("phi_psi", "ca_distances", "backbone_torsions")
 
 def featurize_trajectory(traj, feature_type: str = "phi_psi") -> np.ndarray:
     """(n_frames, n_features) float32: ``"phi_psi"`` -> [phi..., psi...] radians;
-    ``"ca_distances"`` -> all i<j C-alpha pairs (nm); ``"backbone_torsions"`` -> phi, psi
-    (chi1 needs side-chain templates and is not available: raises if requested residues have it)."""
+    ``"ca_distances"`` -> all i<j C-alpha pairs (nm); ``"backbone_torsions"`` -> phi, psi and chi1
+    (N-CA-CB-gamma of every residue that has a gamma atom, residue order)."""
     eng = get_engine()
     if feature_type in ("phi_psi", "backbone_torsions"):
-        quads = np.vstack([traj.topology.phi_indices(), traj.topology.psi_indices()])
+        blocks = [traj.topology.phi_indices(), traj.topology.psi_indices()]
+        if feature_type == "backbone_torsions":
+            blocks.append(traj.topology.chi1_indices())
+        quads = np.vstack(blocks)
         xyz = eng.to_device(np.ascontiguousarray(traj.xyz, np.float32))
         return eng.featurize(xyz, quads=quads).to_host()
     if feature_type == "ca_distances":

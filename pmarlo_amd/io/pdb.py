@@ -77,6 +77,21 @@ class Topology:
                 out.append(quad)
         return np.asarray(out, dtype=np.int32).reshape(-1, 4)
 
+    def chi1_indices(self) -> np.ndarray:
+        """N, CA, CB and the gamma atom (CG, CG1, SG, OG or OG1) of every residue that has them, in
+        residue order (mdtraj.compute_chi1: one pattern matches per residue type)."""
+        out = []
+        for r in range(self.n_residues):
+            head = [self._atom(r, "N"), self._atom(r, "CA"), self._atom(r, "CB")]
+            if None in head:
+                continue
+            for gamma in ("CG", "CG1", "SG", "OG", "OG1"):
+                g = self._atom(r, gamma)
+                if g is not None:
+                    out.append(head + [g])
+                    break
+        return np.asarray(out, dtype=np.int32).reshape(-1, 4)
+
 
 @dataclass
 class Trajectory:

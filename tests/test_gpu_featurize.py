@@ -91,3 +91,45 @@ def test_rg_distance_pair_contacts_pair(engine, golden):
         get_feature("contacts_pair").compute(traj, i=0, j=1, rcut=0.0)
     with pytest.raises(ValueError):
         get_feature("distance_pair").compute(traj, i=0, j=A)
+
+
+def test_chi1_and_backbone_torsions(engine, tmp_path):
+    """chi1 = N-CA-CB-gamma for residues with a gamma atom (mdtraj.compute_chi1's patterns CG, CG1, SG, OG,
+    OG1), residue order; "backbone_torsions" = [phi | psi | chi1] (S/features/featurize.py:55-62)."""
+    from pmarlo_amd.features import featurize_trajectory, get_feature
+    from pmarlo_amd.io import load_pdb
+
+    rng = np.random.default_rng(5)
+    residues = [("GLY", ["N", "CA", "C", "O"]), ("SER", ["N", "CA", "C", "O", "CB", "OG"]),
+                ("VAL", ["N", "CA", "C", "O", "CB", "CG1", "CG2"]), ("ALA", ["N", "CA", "C", "O", "CB"]),
+                ("THR", ["N", "CA", "C", "O", "CB", "OG1", "CG2"]), ("CYS", ["N", "CA", "C", "O", "CB", "SG"]),
+                ("LEU", ["N", "CA", "C", "O", "CB", "CG", "CD1", "CD2"])]
+    lines, names, serial = [], [], 1
+    for model in range(4):
+        lines.append(f"MODEL     {model + 1:4d}")
+        for r, (resn, atoms) in enumerate(residues):
+            for a in atoms:
+                x, y, z = rng.normal(scale=4.0, size=3) + 3.0 * r
+                lines.append(f"ATOM  {serial % 100000:5d} {a:<4s} {resn} A{r + 1:4d}    {x:8.3f}{y:8.3f}{z:8.3f}  1.00  0.00")
+                serial += 1
+                if model == 0:
+                    names.append((r, a))
+        lines.append("ENDMDL")
+    path = tmp_path / "pep.pdb"
+    path.write_text("\n".join(lines) + "\nEND\n")
+    traj = load_pdb(path)
+    assert traj.n_frames == 4
+    at = {ra: i for i, ra in enumerate(names)}
+    want_quads = [[at[(r, "N")], at[(r, "CA")], at[(r, "CB")], at[(r, g)]]
+                  for r, g in ((1, "OG"), (2, "CG1"), (4, "OG1"), (5, "SG"), (6, "CG"))]
+    np.testing.assert_array_equal(traj.topology.chi1_indices(), want_quads)
+    fc = get_feature("chi1")
+    got = fc.compute(traj)
+    want = npport.dihedrals(traj.xyz, np.asarray(want_quads))
+    np.testing.assert_allclose(got, want, atol=2e-5)
+    assert fc.labels == ["chi1:res1", "chi1:res2", "chi1:res4", "chi1:res5", "chi1:res6"] and fc.is_periodic().all()
+    bt = featurize_trajectory(traj, "backbone_torsions")
+    pp = featurize_trajectory(traj, "phi_psi")
+    assert bt.shape == (4, pp.shape[1] + 5)
+    np.testing.assert_array_equal(bt[:, :pp.shape[1]], pp)
+    np.testing.assert_allclose(bt[:, pp.shape[1]:], want, atol=2e-5)
