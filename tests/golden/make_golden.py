@@ -407,7 +407,32 @@ def golden_its_helpers():
     np.savez_compressed(OUT / "its_helpers.npz", **out)
 
 
+def golden_validate():
+    """analysis/validation.validate_features: statistics of a clean matrix, and the error codes / statistics of
+    the three failure modes (non-finite entries, no finite row, zero-variance column)."""
+    from pmarlo.analysis.validation import ValidationError, validate_features
+
+    rng = np.random.default_rng(9)
+    X = rng.normal(size=(400, 5)) * np.array([1.0, 3.0, 0.2, 10.0, 1e-3]) + np.array([0.0, 5.0, -2.0, 100.0, 1.0])
+    cases = {"ok": (X, ["a", "b", "c"])}
+    bad = X.copy(); bad[3, 1] = np.nan; bad[7, 4] = np.inf
+    cases["non_finite"] = (bad, None)
+    none = X[:6].copy(); none[:, 0] = np.nan
+    cases["no_finite_rows"] = (none, ["p", "q", "r", "s", "t", "u"])
+    flat = X.copy(); flat[:, 2] = 4.25
+    cases["zero_std"] = (flat, None)
+    out = {}
+    for name, (M, names) in cases.items():
+        try:
+            out[name] = {"stats": validate_features(M, names), "code": None}
+        except ValidationError as exc:
+            out[name] = {"stats": exc.stats, "code": exc.code}
+    np.savez_compressed(OUT / "validate.npz", X=X)
+    (OUT / "validate.json").write_text(json.dumps(out, indent=1, sort_keys=True, default=float))
+
+
 if __name__ == "__main__":
+    golden_validate()
     golden_its_helpers()
     golden_grid()
     golden_pca()

@@ -386,3 +386,32 @@ def test_vamp_reduce_vs_oracle(engine, n, F, lag, dim, scale):
     np.testing.assert_array_equal(reduce_features(X, method="vamp", n_components=dim, lag=lag, scale=scale), got)
     with pytest.raises(ValueError):
         vamp_reduce(X[:5], lag=10)
+
+
+# ---- validate_features (analysis/validation.py:89-172; golden made with the reference) ------------
+def test_validate_features_vs_reference_golden(engine, golden):
+    from pmarlo_amd.analysis.validation import ValidationError, validate_features
+
+    X = golden("validate.npz")["X"]
+    want = json.loads((GOLDEN / "validate.json").read_text())
+    bad = X.copy(); bad[3, 1] = np.nan; bad[7, 4] = np.inf
+    none = X[:6].copy(); none[:, 0] = np.nan
+    flat = X.copy(); flat[:, 2] = 4.25
+    cases = {"ok": (X, ["a", "b", "c"]), "non_finite": (bad, None),
+             "no_finite_rows": (none, ["p", "q", "r", "s", "t", "u"]), "zero_std": (flat, None)}
+    for name, (M, names) in cases.items():
+        try:
+            stats, code = validate_features(M, names), None
+        except ValidationError as exc:
+            stats, code = exc.stats, exc.code
+        ref = want[name]
+        assert code == ref["code"], name
+        assert sorted(stats) == sorted(ref["stats"]), name
+        for key, val in ref["stats"].items():
+            if key in ("means", "stds", "mins", "maxs"):
+                np.testing.assert_allclose(np.asarray(stats[key], float), np.asarray(val, float), rtol=1e-12,
+                                           atol=1e-12, equal_nan=True, err_msg=f"{name}:{key}")
+            else:
+                assert stats[key] == val, (name, key)
+    with pytest.raises(ValueError):
+        validate_features(np.zeros(5), None)
