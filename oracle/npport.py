@@ -340,7 +340,11 @@ def reversible_its_from_counts(C, lag, n_timescales):
     rs = np.where(row == 0, 1.0, row)
     dinv = 1.0 / np.sqrt(rs)
     S = Cr * dinv[:, None] * dinv[None, :]
-    ev = np.sort(np.linalg.eigvalsh(S))[::-1]
+    ev = np.linalg.eigvalsh(S)
+    ev = ev[np.argsort(-np.abs(ev))]                        # deeptime eigenvalues(T, k): the k largest in magnitude
+    if n_timescales + 1 < ev.size:
+        ev = ev[:n_timescales + 1]
+    ev = np.sort(ev)[::-1]                                  # then by descending value, first (= 1) dropped
     eig = np.clip(np.abs(ev[1:1 + n_timescales]), NUMERIC_MIN_POSITIVE, 1.0 - NUMERIC_MIN_POSITIVE)
     return eig, safe_timescales(int(max(1, lag)), eig)
 

@@ -9,6 +9,7 @@ from .its import (  # noqa: F401
     candidate_lag_ladder,
     compute_implied_timescales,
     detect_timescale_plateau,
+    deterministic_its_from_counts,
     safe_timescales,
     select_lag_from_its,
 )

@@ -21,7 +21,8 @@ from ..device import get_engine
 from .estimation import _concat_dtrajs
 from .results import ITSResult
 
-__all__ = ["safe_timescales", "compute_implied_timescales", "detect_timescale_plateau", "select_lag_from_its",
+__all__ = ["safe_timescales", "compute_implied_timescales", "deterministic_its_from_counts", "detect_timescale_plateau",
+           "select_lag_from_its",
            "candidate_lag_ladder", "DEFAULT_ITS_LAGS"]
 
 EPS = 1e-12
@@ -132,6 +133,28 @@ def select_lag_from_its(lag_times, timescales, *, min_lag_idx: int = 3, plateau_
     return int(lags[n // 2])
 
 
+def deterministic_its_from_counts(counts: np.ndarray, lag: int, n_timescales: int):
+    """(eigenvalues, timescales, rates) of the symmetrised estimate T = rownorm((C + C') / 2): the fall-back of
+    ITSMixin._deterministic_its_from_counts (S/markov_state_model/_its.py:742-801) in its mathematically
+    intended form -- the reference takes pi from the row sums of T (identically 1), which de-symmetrises
+    deeptime's similarity transform; that quirk is not replicated.  Spectrum on the device."""
+    C = np.asarray(counts, dtype=np.float64)
+    n = int(n_timescales)
+    ev, ts = np.zeros(n), np.full(n, np.nan)
+    k = C.shape[0]
+    if n > 0 and k > 0:
+        eng = get_engine()
+        T = eng.transition_matrix(eng.to_device(np.ascontiguousarray(0.5 * (C + C.T))), mode=0)["T"]
+        want = min(n, max(k - 1, 0))
+        if want > 0:
+            spec = eng.spectrum(T, n_its=want, lags=[float(max(1, int(lag)))], want_pi=False, allow_unconverged=True)
+            ev[:want] = np.nan_to_num(spec["its_eig"][0], nan=0.0)
+            ts[:want] = spec["its_ts"][0]
+    with np.errstate(divide="ignore", invalid="ignore"):
+        rates = np.where(np.isfinite(ts), 1.0 / ts, np.nan)
+    return ev, ts, rates
+
+
 def _posterior_summary(ev: np.ndarray, ts: np.ndarray, q_low: float, q_high: float):
     """Median and percentile band over the sample axis (axis 1) of [L, S, n] arrays
     (_summarize_its_stats, S/markov_state_model/_its.py:606-625)."""
@@ -217,12 +240,14 @@ def compute_implied_timescales(dtrajs: Sequence[np.ndarray], n_states: int, lag_
         samples = {"eigenvalues": ev_s, "timescales": ts_s}
         dead = ~np.isfinite(ts).any(axis=1)
         if dead.any():
-            # _its_fill_missing_timescales :403-419 falls back to a deterministic estimate for lags whose
-            # samples gave no finite timescale; here: the maximum-likelihood matrix of that lag
-            spec = eng.spectrum(Tb, n=nb, n_its=n, lags=[float(v) for v in lags], want_pi=False)
-            ev[dead], ts[dead] = spec["its_eig"][dead], spec["its_ts"][dead]
-            with np.errstate(divide="ignore", invalid="ignore"):
-                rates[dead] = np.where(np.isfinite(ts[dead]), 1.0 / ts[dead], np.nan)
+            # _its_fill_missing_timescales :403-419: lags whose samples gave no finite timescale take the
+            # deterministic estimate from the regularised counts of that lag (_counts_for_lag)
+            from .estimation import ensure_connected_counts
+
+            for i in np.flatnonzero(dead):
+                Ci = counts.view((k, k), offset_elems=int(i) * k * k).to_host().astype(float)
+                ev[i], ts[i], rates[i] = deterministic_its_from_counts(
+                    ensure_connected_counts(Ci, alpha=float(dirichlet_alpha)).counts, lags[i], n)
     res = ITSResult(lag_times=np.asarray(lags, dtype=int), eigenvalues=ev, eigenvalues_ci=ev_ci, timescales=ts,
                     timescales_ci=ts_ci, rates=rates, rates_ci=rate_ci)
     if plateau_m is not None and plateau_m >= 1 and L > 1:          # _its_optionally_attach_plateau :381-401

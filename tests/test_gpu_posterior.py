@@ -147,3 +147,20 @@ def test_bayesian_its_two_state(engine):
     win = compute_implied_timescales([traj], 2, lag_times=lags, n_timescales=1, n_samples=0, plateau_m=3,
                                      plateau_epsilon=0.2, time_per_frame_ps=2.0).recommended_lag_window
     assert win == (2.0, 10.0)
+
+
+def test_deterministic_its_from_counts(engine):
+    """Fall-back estimate: spectrum of rownorm((C + C') / 2) against the numpy restatement of the intended form."""
+    from pmarlo_amd.markov_state_model import deterministic_its_from_counts
+
+    rng = np.random.default_rng(2)
+    C = rng.poisson(2.0, size=(30, 30)).astype(float)
+    for b in range(3):
+        C[10 * b:10 * b + 10, 10 * b:10 * b + 10] += rng.poisson(40.0, size=(10, 10))
+    ev, ts, rates = deterministic_its_from_counts(C, 4, 3)
+    ev_ref, ts_ref = npport.reversible_its_from_counts(C, 4, 3)
+    np.testing.assert_allclose(ev, ev_ref, rtol=1e-9)
+    np.testing.assert_allclose(ts, ts_ref, rtol=1e-8)
+    np.testing.assert_allclose(rates, 1.0 / ts_ref, rtol=1e-8)
+    ev2, ts2, _ = deterministic_its_from_counts(C[:2, :2], 1, 4)          # more timescales than the chain has
+    assert np.isfinite(ts2[0]) and np.all(np.isnan(ts2[1:])) and np.all(ev2[1:] == 0.0)
