@@ -467,7 +467,8 @@ msm_status msm_diff_norms(msm_ctx* ctx, const double* d_P, int64_t ldp, const do
  *   entry, bit 1 total <= 0, bit 2 entry <= 0 (the reference raises for each).
  * msm_kde2d: density[i][j] = 1/(2 pi bw_x bw_y) sum_k w_k w_scale exp(-((xc_i - x_k)/bw_x)^2/2)
  *   exp(-((yc_j - y_k)/bw_y)^2/2) on the matrix cores (:176-238); d_w NULL = all weights
- *   w_scale. */
+ *   w_scale.  periodic bit 0 / bit 1: the x / y difference is wrapped to [-pi, pi) first (wrapped
+ *   Gaussian on the torus: periodic_kde_2d, S/markov_state_model/free_energy.py:321-360). */
 msm_status msm_weighted_stats(msm_ctx* ctx, const double* d_x, int64_t stride, int64_t n,
                               const double* d_w, double* d_out6);
 msm_status msm_hist2d(msm_ctx* ctx, const double* d_x, int64_t sx, const double* d_y, int64_t sy,
@@ -480,7 +481,7 @@ msm_status msm_fes_finalize(msm_ctx* ctx, const double* d_hist, int n_cells, dou
                             double* d_F, int32_t* d_status);
 msm_status msm_kde2d(msm_ctx* ctx, const double* d_x, int64_t sx, const double* d_y, int64_t sy,
                      int64_t n, const double* d_w, double w_scale, const double* d_xcenters, int nx,
-                     const double* d_ycenters, int ny, double bw_x, double bw_y, double* d_density);
+                     const double* d_ycenters, int ny, double bw_x, double bw_y, int periodic, double* d_density);
 
 /* ---- dense solves on T: committors, reactive flux, lumping, MFPT ---------------------------
  * msm_solve_f64: A X = B by Gaussian elimination with partial pivoting (first maximal pivot),

@@ -1096,3 +1096,39 @@ def vamp_reduce(X, lag=1, n_components=2, scale=True, epsilon=1e-6):
     for j in range(dim):
         W[:, j] *= np.sign(W[np.argmax(np.abs(W[:, j])), j])
     return (Z - a0) @ W, s
+
+
+# ---- densities to free energies (S/markov_state_model/free_energy.py:257-414) ----------------------
+def free_energy_from_density(density, temperature, mask=None, inpaint=False, tiny=None):
+    rho = np.asarray(density, dtype=np.float64)
+    floor = np.finfo(np.float64).tiny if tiny is None else float(tiny)
+    kT = 1.380649e-23 * float(temperature) * 6.02214076e23 / 1000.0
+    F = np.full(rho.shape, np.inf)
+    ok = rho > floor
+    F[ok] = -kT * np.log(rho[ok])
+    if mask is not None and not inpaint:
+        F[np.asarray(mask, dtype=bool)] = np.nan
+    if np.isfinite(F).any():
+        F = F - np.nanmin(F)
+    return F
+
+
+def periodic_kde_2d(theta_x, theta_y, bw=(0.35, 0.35), gridsize=(42, 42)):
+    x, y = np.asarray(theta_x, float).ravel(), np.asarray(theta_y, float).ravel()
+    gx = np.linspace(-np.pi, np.pi, gridsize[0], endpoint=False)
+    gy = np.linspace(-np.pi, np.pi, gridsize[1], endpoint=False)
+    wrap = lambda a: np.remainder(a + np.pi, 2.0 * np.pi) - np.pi  # noqa: E731
+    ex = np.exp(-0.5 * (wrap(gx[:, None] - x[None, :]) / bw[0]) ** 2)       # [gx, N]
+    ey = np.exp(-0.5 * (wrap(gy[:, None] - y[None, :]) / bw[1]) ** 2)       # [gy, N]
+    return ex @ ey.T / (x.size * 2.0 * np.pi * bw[0] * bw[1])
+
+
+def pmf_1d(cv, bins=100, temperature=300.0, periodic=False, range_=None, smoothing_sigma=None):
+    from scipy.ndimage import gaussian_filter
+
+    cv = np.asarray(cv, float).ravel()
+    rng_ = (float(cv.min()), float(cv.max())) if range_ is None else (float(range_[0]), float(range_[1]))
+    H, edges = np.histogram(cv, bins=bins, range=rng_, density=True)
+    if smoothing_sigma and smoothing_sigma > 0:
+        H = gaussian_filter(H, sigma=float(smoothing_sigma), mode="wrap" if periodic else "reflect")
+    return free_energy_from_density(H, temperature), edges, H

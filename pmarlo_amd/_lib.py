@@ -93,7 +93,7 @@ _PROTOTYPES: dict[str, tuple] = {
     "msm_smooth_sparse_bins": (_i32, [_vp, _vp, _i32, _i32, _f64, _vp, _vp]),
     "msm_scale_to_total": (_i32, [_vp, _vp, _i32, _f64]),
     "msm_fes_finalize": (_i32, [_vp, _vp, _i32, _f64, _vp, _vp]),
-    "msm_kde2d": (_i32, [_vp, _vp, _i64, _vp, _i64, _i64, _vp, _f64, _vp, _i32, _vp, _i32, _f64, _f64, _vp]),
+    "msm_kde2d": (_i32, [_vp, _vp, _i64, _vp, _i64, _i64, _vp, _f64, _vp, _i32, _vp, _i32, _f64, _f64, _i32, _vp]),
     "msm_solve_f64": (_i32, [_vp, _i32, _i32, _vp, _i64, _vp, _i64, _vp]),
     "msm_reactive_flux": (_i32, [_vp, _vp, _i64, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp]),
     "msm_lump_macro": (_i32, [_vp, _vp, _i64, _vp, _vp, _i32, _i32, _vp, _vp]),

@@ -231,11 +231,19 @@ __global__ __launch_bounds__(1024) void fes_finalize_kernel(const double* __rest
 // MFMA operands per 4 frames: A lane l = ex_{16 rb + (l & 15)}(frame k0 + (l >> 4)), B likewise
 // ey * w; D reg r of tile (rb, cb) = density[16 rb + (l >> 4) + 4 r][16 cb + (l & 15)].
 // ---------------------------------------------------------------------------------------------
+// ((a + pi) mod 2 pi) - pi with numpy's sign convention for the remainder (result in [-pi, pi))
+__device__ __forceinline__ double wrap_angle(double a) {
+    const double two_pi = 6.283185307179586, pi = 3.141592653589793;
+    double m = fmod(a + pi, two_pi);
+    if (m < 0.0) m += two_pi;
+    return m - pi;
+}
+
 __global__ __launch_bounds__(256, 2) void kde2d_kernel(const double* __restrict__ x, int64_t sx, const double* __restrict__ y,
                                                        int64_t sy, int64_t n, const double* __restrict__ w, double w_scale,
                                                        const double* __restrict__ xcen, int nx,
                                                        const double* __restrict__ ycen, int ny, double inv_bwx,
-                                                       double inv_bwy, double* __restrict__ slabs) {
+                                                       double inv_bwy, int periodic, double* __restrict__ slabs) {
     __shared__ double acc_lds[64 * 64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int i0 = blockIdx.y * 64, j0 = blockIdx.z * 64;
@@ -262,7 +270,10 @@ __global__ __launch_bounds__(256, 2) void kde2d_kernel(const double* __restrict_
         double ea[4], eb[4];
 #pragma unroll
         for (int b = 0; b < 4; ++b) {
-            const double u = (xc[b] - xv) * inv_bwx, v = (yc[b] - yv) * inv_bwy;
+            double dx = xc[b] - xv, dy = yc[b] - yv;
+            if (periodic & 1) dx = wrap_angle(dx);     // toroidal coordinate: nearest image
+            if (periodic & 2) dy = wrap_angle(dy);
+            const double u = dx * inv_bwx, v = dy * inv_bwy;
             ea[b] = exp(-0.5 * (u * u));
             eb[b] = exp(-0.5 * (v * v)) * wv;
         }
@@ -391,9 +402,10 @@ msm_status msm_fes_finalize(msm_ctx* ctx, const double* d_hist, int n_cells, dou
 
 msm_status msm_kde2d(msm_ctx* ctx, const double* d_x, int64_t sx, const double* d_y, int64_t sy, int64_t n,
                      const double* d_w, double w_scale, const double* d_xcenters, int nx, const double* d_ycenters, int ny,
-                     double bw_x, double bw_y, double* d_density) {
+                     double bw_x, double bw_y, int periodic, double* d_density) {
     if (!ctx) return MSM_ERR_INVALID;
     MSM_REQUIRE(ctx, n >= 1 && nx >= 1 && ny >= 1 && nx <= 4096 && ny <= 4096, "msm_kde2d: bad shape");
+    MSM_REQUIRE(ctx, periodic >= 0 && periodic <= 3, "msm_kde2d: periodic is a 2-bit mask (1 = x, 2 = y)");
     MSM_REQUIRE(ctx, d_x && d_y && d_density && d_xcenters && d_ycenters && bw_x > 0.0 && bw_y > 0.0,
                 "msm_kde2d: bad arguments");
     const int nby = (nx + 63) / 64, nbz = (ny + 63) / 64;
@@ -405,7 +417,7 @@ msm_status msm_kde2d(msm_ctx* ctx, const double* d_x, int64_t sx, const double* 
     if (rs != MSM_OK) return rs;
     double* slabs = (double*)ctx->scratch;
     hipLaunchKernelGGL(kde2d_kernel, dim3(gx, nby, nbz), dim3(256), 0, ctx->stream, d_x, sx, d_y, sy, n, d_w, w_scale,
-                       d_xcenters, nx, d_ycenters, ny, 1.0 / bw_x, 1.0 / bw_y, slabs);
+                       d_xcenters, nx, d_ycenters, ny, 1.0 / bw_x, 1.0 / bw_y, periodic, slabs);
     MSM_CHECK_LAUNCH(ctx);
     const double normaliser = 1.0 / (2.0 * 3.14159265358979323846 * bw_x * bw_y);
     hipLaunchKernelGGL(kde_reduce_kernel, dim3((nx * ny + 255) / 256), dim3(256), 0, ctx->stream, slabs, gx, nby, nbz, nx,

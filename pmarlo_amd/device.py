@@ -630,13 +630,14 @@ class Engine:
         return F, int(st.to_host()[0])
 
     def kde2d(self, x: DeviceArray, cols, xcenters: np.ndarray, ycenters: np.ndarray, bw_x: float, bw_y: float,
-              weights: DeviceArray | None, w_scale: float) -> DeviceArray:
+              weights: DeviceArray | None, w_scale: float, periodic: int = 0) -> DeviceArray:
+        """periodic: bit 0 / bit 1 wrap the x / y differences to [-pi, pi) (density on a torus)."""
         n, d = x.shape
         xc, yc = self.to_device(np.ascontiguousarray(xcenters, np.float64)), self.to_device(np.ascontiguousarray(ycenters, np.float64))
         dens = self.empty((len(xcenters), len(ycenters)), np.float64)
         check(lib.msm_kde2d(self.handle, x.ptr + int(cols[0]) * 8, d, x.ptr + int(cols[1]) * 8, d, n,
                             weights.ptr if weights is not None else None, float(w_scale), xc.ptr, len(xcenters), yc.ptr,
-                            len(ycenters), float(bw_x), float(bw_y), dens.ptr), self.handle)
+                            len(ycenters), float(bw_x), float(bw_y), int(periodic), dens.ptr), self.handle)
         return dens
 
     def gemm(self, A: DeviceArray, B: DeviceArray, out: DeviceArray | None = None) -> DeviceArray:

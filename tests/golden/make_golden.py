@@ -431,7 +431,37 @@ def golden_validate():
     (OUT / "validate.json").write_text(json.dumps(out, indent=1, sort_keys=True, default=float))
 
 
+def golden_free_energy():
+    """markov_state_model/free_energy.py (imports without deeptime): periodic_kde_2d, free_energy_from_density,
+    generate_1d_pmf on seeded samples."""
+    from pmarlo.markov_state_model import free_energy as fe
+
+    rng = np.random.default_rng(31)
+    n = 2500
+    tx = np.concatenate([rng.vonmises(-2.8, 4.0, n // 2), rng.vonmises(1.0, 8.0, n - n // 2)])
+    ty = np.concatenate([rng.vonmises(3.0, 6.0, n // 2), rng.vonmises(-0.5, 3.0, n - n // 2)])
+    out = dict(tx=tx, ty=ty, kde_default=fe.periodic_kde_2d(tx, ty),
+               kde_fine=fe.periodic_kde_2d(tx, ty, bw=(0.2, 0.5), gridsize=(30, 70)))
+    dens = out["kde_default"].copy()
+    dens[3, :5] = 0.0
+    mask = dens < 0.002
+    out.update(dens=dens, mask=mask, F_plain=fe.free_energy_from_density(dens, 300.0),
+               F_mask=fe.free_energy_from_density(dens, 310.0, mask=mask),
+               F_inpaint=fe.free_energy_from_density(dens, 310.0, mask=mask, inpaint=True),
+               F_tiny=fe.free_energy_from_density(dens, 300.0, tiny=0.01))
+    cv = np.concatenate([rng.normal(-1.0, 0.4, 4000), rng.normal(1.5, 0.7, 3000)])
+    for name, kw in (("pmf_plain", dict(bins=60)), ("pmf_smooth", dict(bins=80, smoothing_sigma=1.5)),
+                     ("pmf_periodic", dict(bins=36, periodic=True, range_=(-np.pi, np.pi), smoothing_sigma=0.8)),
+                     ("pmf_range", dict(bins=25, range_=(-0.5, 2.0), temperature=350.0))):
+        data = tx if name == "pmf_periodic" else cv
+        r = fe.generate_1d_pmf(data, **kw)
+        out.update({f"{name}_F": r.F, f"{name}_edges": r.edges, f"{name}_counts": r.counts})
+    out["cv"] = cv
+    np.savez_compressed(OUT / "free_energy.npz", **out)
+
+
 if __name__ == "__main__":
+    golden_free_energy()
     golden_validate()
     golden_its_helpers()
     golden_grid()
