@@ -163,6 +163,14 @@ msm_status msm_count_transitions_lagscan(msm_ctx* ctx, const int32_t* d_labels, 
 msm_status msm_state_counts(msm_ctx* ctx, const int32_t* d_labels, int64_t n, int k,
                             int64_t* d_visits);
 
+/* Dwell times (runs of one state) of a label sequence in which negative labels separate trajectories
+ * (_compute_dwell_times, S/analysis/debug_export.py:447-530, after its removal of unassigned frames):
+ * d_stats int64 [4][k] = {min, max, sum, number} of the run lengths per state (min = -1 for a state
+ * without runs); every run is also appended, in no particular order, to d_run_state int32 / d_run_len
+ * int64 [capacity] (for the medians; capacity >= number of runs, at most n), *d_n_runs = runs found. */
+msm_status msm_run_lengths(msm_ctx* ctx, const int32_t* d_labels, int64_t n, int k, int64_t* d_stats,
+                           int32_t* d_run_state, int64_t* d_run_len, int64_t capacity, int64_t* d_n_runs);
+
 /* ------------------------------------------------------------------ */
 /* standardisation moments, time-lagged covariance, TICA               */
 /* ------------------------------------------------------------------ */

@@ -203,6 +203,35 @@ msm_status launch_counts(msm_ctx* ctx, const int32_t* d_labels, const double* d_
 
 }  // namespace
 
+namespace {
+
+// Dwell times: a run starts at frame t when label[t] is a state and differs from label[t-1] (negative
+// labels act as separators between trajectories); the starting thread walks to the end of its run.
+// Per state: min / max / sum of the run lengths and the number of runs (64-bit integer atomics: order
+// free, exact); every run is also appended to a list for the medians.
+__global__ __launch_bounds__(256) void run_lengths_kernel(const int32_t* __restrict__ labels, int64_t n, int k,
+                                                          unsigned long long* __restrict__ stats,
+                                                          int32_t* __restrict__ run_state,
+                                                          long long* __restrict__ run_len, long long cap,
+                                                          unsigned long long* __restrict__ n_runs) {
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (int64_t)gridDim.x * blockDim.x) {
+        const int s = labels[t];
+        if (s < 0 || s >= k) continue;
+        if (t > 0 && labels[t - 1] == s) continue;
+        int64_t u = t + 1;
+        while (u < n && labels[u] == s) ++u;
+        const unsigned long long len = (unsigned long long)(u - t);
+        atomicMin(&stats[s], len);
+        atomicMax(&stats[(size_t)k + s], len);
+        atomicAdd(&stats[2 * (size_t)k + s], len);
+        atomicAdd(&stats[3 * (size_t)k + s], 1ull);
+        const unsigned long long slot = atomicAdd(n_runs, 1ull);
+        if ((long long)slot < cap) { run_state[slot] = s; run_len[slot] = (long long)len; }
+    }
+}
+
+}  // namespace
+
 extern "C" {
 
 msm_status msm_count_transitions(msm_ctx* ctx, const int32_t* d_labels, int64_t n,
@@ -267,6 +296,24 @@ msm_status msm_state_counts(msm_ctx* ctx, const int32_t* d_labels, int64_t n, in
     const size_t lds = k <= 16384 ? (size_t)k * sizeof(unsigned int) : 0;
     hipLaunchKernelGGL(state_counts_kernel, dim3(blocks), dim3(kThreads), lds, ctx->stream, d_labels, n, k,
                        (unsigned long long*)d_visits);
+    MSM_CHECK_LAUNCH(ctx);
+    return MSM_OK;
+}
+
+msm_status msm_run_lengths(msm_ctx* ctx, const int32_t* d_labels, int64_t n, int k, int64_t* d_stats,
+                           int32_t* d_run_state, int64_t* d_run_len, int64_t capacity, int64_t* d_n_runs) {
+    if (!ctx) return MSM_ERR_INVALID;
+    MSM_REQUIRE(ctx, n >= 0 && k >= 1 && capacity >= 0, "msm_run_lengths: bad shape");
+    MSM_REQUIRE(ctx, d_stats && d_n_runs && (d_labels || n == 0) && (capacity == 0 || (d_run_state && d_run_len)),
+                "msm_run_lengths: NULL pointer");
+    MSM_HIP(ctx, hipMemsetAsync(d_stats, 0xFF, (size_t)k * sizeof(int64_t), ctx->stream));            // min: all ones
+    MSM_HIP(ctx, hipMemsetAsync(d_stats + k, 0, (size_t)3 * k * sizeof(int64_t), ctx->stream));
+    MSM_HIP(ctx, hipMemsetAsync(d_n_runs, 0, sizeof(int64_t), ctx->stream));
+    if (n == 0) return MSM_OK;
+    const int blocks = (int)std::min<int64_t>(std::max<int64_t>(1, msm_ceil_div(n, 256 * 4)), (int64_t)ctx->n_cu * 8);
+    hipLaunchKernelGGL(run_lengths_kernel, dim3(blocks), dim3(256), 0, ctx->stream, d_labels, n, k,
+                       (unsigned long long*)d_stats, d_run_state, (long long*)d_run_len, (long long)capacity,
+                       (unsigned long long*)d_n_runs);
     MSM_CHECK_LAUNCH(ctx);
     return MSM_OK;
 }

@@ -320,6 +320,17 @@ class Engine:
         check(lib.msm_state_counts(self.handle, labels.ptr, labels.size, int(k), out.ptr), self.handle)
         return out
 
+    def run_lengths(self, labels: DeviceArray, k: int):
+        """Dwell-time runs of a label sequence (negative labels separate trajectories) ->
+        (stats int64 [4, k] = min / max / sum / number per state, run states int32 [R], run lengths int64 [R])."""
+        n = labels.size
+        stats = self.empty((4, int(k)), np.int64)
+        rs, rl = self.empty((max(n, 1),), np.int32), self.empty((max(n, 1),), np.int64)
+        cnt = self.empty((1,), np.int64)
+        check(lib.msm_run_lengths(self.handle, labels.ptr, n, int(k), stats.ptr, rs.ptr, rl.ptr, n, cnt.ptr), self.handle)
+        r = int(cnt.to_host()[0])
+        return stats.to_host(), rs.to_host()[:r], rl.to_host()[:r]
+
     # -- moments / covariance / TICA -------------------------------------------
     def column_moments(self, x: DeviceArray, ddof: int = 0):
         """-> (mean, std, count) device arrays [F] f64 (NaN entries skipped)."""

@@ -460,7 +460,39 @@ def golden_free_energy():
     np.savez_compressed(OUT / "free_energy.npz", **out)
 
 
+def golden_debug():
+    """analysis/debug_export.compute_analysis_debug: full summaries (counts, visits, SCC, dwell times, warnings)
+    for sliding and strided counting, unassigned frames, an isolated and a sink-only state."""
+    rng = np.random.default_rng(77)
+
+    def chain(n, k, stay, seed):
+        r = np.random.default_rng(seed)
+        x = np.zeros(n, dtype=int)
+        for t in range(1, n):
+            x[t] = x[t - 1] if r.random() < stay else r.integers(k)
+        return x
+
+    a = chain(9000, 8, 0.9, 1)
+    b = chain(4000, 8, 0.7, 2)
+    b[[1200, 2900]] = -1            # two unassigned frames (more would trip the reference's pair-count check)
+    c = chain(700, 6, 0.5, 3)
+    c[-1] = 9                      # state 9 is only ever entered (zero row), state 8 never seen
+    cases = {"sliding": ([a, b, c], 3, "sliding"), "strided": ([a, b], 4, "strided"),
+             "tiny": ([c[:200], np.array([], dtype=int), np.full(5, -1)], 2, "sliding")}
+    arrays, summaries = {}, {}
+    for name, (dtrajs, lag, mode) in cases.items():
+        dbg = compute_analysis_debug({"dtrajs": dtrajs}, lag=lag, count_mode=mode)
+        summaries[name] = dbg.to_summary_dict()
+        arrays[f"{name}_counts"] = dbg.counts
+        for i, d in enumerate(dtrajs):
+            arrays[f"{name}_dtraj{i}"] = np.asarray(d, dtype=np.int64)
+        summaries[name]["_lag"], summaries[name]["_mode"], summaries[name]["_n_dtrajs"] = lag, mode, len(dtrajs)
+    np.savez_compressed(OUT / "debug.npz", **arrays)
+    (OUT / "debug.json").write_text(json.dumps(summaries, indent=1, sort_keys=True, default=float))
+
+
 if __name__ == "__main__":
+    golden_debug()
     golden_free_energy()
     golden_validate()
     golden_its_helpers()
