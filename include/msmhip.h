@@ -459,6 +459,14 @@ msm_status msm_ck_test(msm_ctx* ctx, const double* d_T1, int64_t ld1, const doub
 msm_status msm_diff_norms(msm_ctx* ctx, const double* d_P, int64_t ldp, const double* d_Q, int64_t ldq, int n, int m,
                           double* d_out);
 
+/* Exact order statistics: h_out[q] = the h_ranks[q]-th smallest (0-based) of the n strided samples, by radix
+ * selection on the order-preserving integer image of the doubles (six 12-bit histogram passes per rank; no
+ * sort).  Feeds the quantile rules of the free-energy grids (mquantiles / iqr in generate_2d_fes,
+ * S/markov_state_model/free_energy.py:494-590) and medians.  Samples must not be NaN.  Polls the host
+ * between passes: synchronises the stream, cannot be captured. */
+msm_status msm_order_statistics(msm_ctx* ctx, const double* d_x, int64_t stride, int64_t n, const int64_t* h_ranks,
+                                int n_ranks, double* h_out);
+
 /* ---- free-energy surfaces (S/analysis/fes.py) -----------------------------
  * msm_weighted_stats: d_out6 = {sum w, sum w^2, weighted mean, weighted variance (around that
  *   mean, / sum w), min, max} of the strided coordinate x[i * stride]; d_w NULL = unit weights

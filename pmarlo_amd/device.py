@@ -612,6 +612,18 @@ class Engine:
                                      out.ptr), self.handle)
         return out.to_host()
 
+    def order_statistics(self, x: DeviceArray, ranks, col: int = 0) -> np.ndarray:
+        """The ranks[q]-th smallest values (0-based) of column `col` of x [n, d] (or of a 1-D array)."""
+        if len(x.shape) == 1:
+            n, stride, off = x.shape[0], 1, 0
+        else:
+            n, stride, off = x.shape[0], x.shape[1], int(col)
+        r = np.ascontiguousarray(ranks, dtype=np.int64).ravel()
+        out = np.empty(r.size, dtype=np.float64)
+        check(lib.msm_order_statistics(self.handle, x.ptr + off * 8, stride, n, r.ctypes.data, r.size, out.ctypes.data),
+              self.handle)
+        return out
+
     def hist2d(self, x: DeviceArray, cols, xedges: np.ndarray, yedges: np.ndarray,
                weights: DeviceArray | None = None, w_absmax: float = 0.0) -> DeviceArray:
         """np.histogram2d(x[:, cols[0]], x[:, cols[1]], bins=[xedges, yedges], weights=w) -> f64 [nx, ny]."""

@@ -129,3 +129,21 @@ def test_free_energy_module_vs_reference_golden(golden):
         generate_1d_pmf(g["cv"], bins=0)
     with pytest.raises(ValueError):
         free_energy_from_density(d, 0.0)
+
+
+def test_order_statistics_radix_select(engine):
+    """msm_order_statistics: exact k-th smallest by digit-wise histogram selection, against np.sort."""
+    rng = np.random.default_rng(12)
+    for n, d in ((1, 1), (7, 1), (100_003, 2), (1_000_000, 3)):
+        X = rng.normal(size=(n, d)) * 10.0 ** rng.integers(-3, 4, size=d)
+        X[rng.integers(0, n, size=max(1, n // 10))] = np.round(X[rng.integers(0, n, size=max(1, n // 10))], 1)   # ties
+        if n > 10:
+            X[:5, 0] = [0.0, -0.0, 1e-310, -1e-310, np.inf]
+        xd = engine.to_device(np.ascontiguousarray(X))
+        for col in range(d):
+            ranks = np.unique(np.concatenate([[0, n - 1, n // 2, (n - 1) // 2], rng.integers(0, n, size=6)]))
+            got = engine.order_statistics(xd, ranks, col=col)
+            want = np.sort(X[:, col])[ranks]
+            np.testing.assert_array_equal(got, want)
+    with pytest.raises(ValueError):
+        engine.order_statistics(engine.to_device(np.zeros((4, 1))), [4])
