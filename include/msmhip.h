@@ -499,6 +499,11 @@ msm_status msm_kde2d(msm_ctx* ctx, const double* d_x, int64_t sx, const double* 
                      int64_t n, const double* d_w, double w_scale, const double* d_xcenters, int nx,
                      const double* d_ycenters, int ny, double bw_x, double bw_y, int periodic, double* d_density);
 
+/* d_out[t] = np.clip(x[t], lo, hi) (mode 1) or ((x[t] - lo) % (hi - lo)) + lo with numpy's remainder (mode 2):
+ * the sample preparation of generate_2d_fes (S/markov_state_model/free_energy.py:494-556). */
+msm_status msm_clip_or_wrap(msm_ctx* ctx, const double* d_x, int64_t stride, int64_t n, double lo, double hi, int mode,
+                            double* d_out);
+
 /* ---- dense solves on T: committors, reactive flux, lumping, MFPT ---------------------------
  * msm_solve_f64: A X = B by Gaussian elimination with partial pivoting (first maximal pivot),
  *   one workgroup; d_A [n, lda] is overwritten by the factors, d_B [n, ldb] by X.

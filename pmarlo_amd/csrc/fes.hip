@@ -317,6 +317,26 @@ __global__ void kde_reduce_kernel(const double* __restrict__ slabs, int n_slabs,
 
 }  // namespace
 
+namespace {
+// mode 1: np.clip(x, lo, hi);  mode 2: ((x - lo) % (hi - lo)) + lo with numpy's remainder (result in [lo, hi))
+__global__ __launch_bounds__(256) void clip_or_wrap_kernel(const double* __restrict__ x, int64_t stride, int64_t n,
+                                                           double lo, double hi, int mode, double* __restrict__ out) {
+    const double span = hi - lo;
+    for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < n; t += (int64_t)gridDim.x * 256) {
+        const double v = x[t * stride];
+        double r;
+        if (mode == 1) {
+            r = fmin(fmax(v, lo), hi);
+        } else {
+            r = fmod(v - lo, span);
+            if (r != 0.0) { if (r < 0.0) r += span; } else r = 0.0;
+            r += lo;
+        }
+        out[t] = r;
+    }
+}
+}  // namespace
+
 extern "C" {
 
 msm_status msm_weighted_stats(msm_ctx* ctx, const double* d_x, int64_t stride, int64_t n, const double* d_w,
@@ -422,6 +442,18 @@ msm_status msm_kde2d(msm_ctx* ctx, const double* d_x, int64_t sx, const double* 
     const double normaliser = 1.0 / (2.0 * 3.14159265358979323846 * bw_x * bw_y);
     hipLaunchKernelGGL(kde_reduce_kernel, dim3((nx * ny + 255) / 256), dim3(256), 0, ctx->stream, slabs, gx, nby, nbz, nx,
                        ny, normaliser, d_density);
+    MSM_CHECK_LAUNCH(ctx);
+    return MSM_OK;
+}
+
+msm_status msm_clip_or_wrap(msm_ctx* ctx, const double* d_x, int64_t stride, int64_t n, double lo, double hi, int mode,
+                            double* d_out) {
+    if (!ctx) return MSM_ERR_INVALID;
+    MSM_REQUIRE(ctx, d_x && d_out && n >= 0 && stride >= 1, "msm_clip_or_wrap: bad arguments");
+    MSM_REQUIRE(ctx, (mode == 1 || mode == 2) && lo < hi, "msm_clip_or_wrap: mode 1 = clip, 2 = wrap; need lo < hi");
+    if (n == 0) return MSM_OK;
+    const int blocks = (int)std::min<int64_t>(std::max<int64_t>(1, (n + 1023) / 1024), (int64_t)ctx->n_cu * 8);
+    hipLaunchKernelGGL(clip_or_wrap_kernel, dim3(blocks), dim3(256), 0, ctx->stream, d_x, stride, n, lo, hi, mode, d_out);
     MSM_CHECK_LAUNCH(ctx);
     return MSM_OK;
 }

@@ -612,6 +612,33 @@ class Engine:
                                      out.ptr), self.handle)
         return out.to_host()
 
+    def hist2d_xy(self, x, y, xedges: np.ndarray, yedges: np.ndarray) -> DeviceArray:
+        """np.histogram2d (unweighted) of two device columns on the given edges -> f64 [nx, ny].  x and y are
+        (array, column) pairs for columns of 2-D arrays, or 1-D arrays."""
+        def col(a):
+            if isinstance(a, tuple):
+                arr, c = a
+                return arr.ptr + int(c) * 8, arr.shape[1], arr.shape[0]
+            return a.ptr, 1, a.size
+        (px, sx, n), (py, sy, _) = col(x), col(y)
+        nx, ny = len(xedges) - 1, len(yedges) - 1
+        xe = self.to_device(np.ascontiguousarray(xedges, np.float64))
+        ye = self.to_device(np.ascontiguousarray(yedges, np.float64))
+        h = self.empty((nx, ny), np.float64)
+        check(lib.msm_hist2d(self.handle, px, sx, py, sy, n, None, 0.0, xe.ptr, nx, ye.ptr, ny, h.ptr), self.handle)
+        return h
+
+    def clip_or_wrap(self, x: DeviceArray, lo: float, hi: float, *, wrap: bool, col: int = 0) -> DeviceArray:
+        """New 1-D array: np.clip(x, lo, hi), or ((x - lo) % (hi - lo)) + lo when wrap."""
+        if len(x.shape) == 1:
+            n, stride, off = x.shape[0], 1, 0
+        else:
+            n, stride, off = x.shape[0], x.shape[1], int(col)
+        out = self.empty((n,), np.float64)
+        check(lib.msm_clip_or_wrap(self.handle, x.ptr + off * 8, stride, n, float(lo), float(hi), 2 if wrap else 1,
+                                   out.ptr), self.handle)
+        return out
+
     def order_statistics(self, x: DeviceArray, ranks, col: int = 0) -> np.ndarray:
         """The ranks[q]-th smallest values (0-based) of column `col` of x [n, d] (or of a 1-D array)."""
         if len(x.shape) == 1:

@@ -491,7 +491,40 @@ def golden_debug():
     (OUT / "debug.json").write_text(json.dumps(summaries, indent=1, sort_keys=True, default=float))
 
 
+def golden_fes2d():
+    """markov_state_model/free_energy.generate_2d_fes: adaptive / fixed grids, a periodic torus, given ranges,
+    and the three smoothing modes."""
+    from pmarlo.markov_state_model.free_energy import generate_2d_fes
+
+    rng = np.random.default_rng(41)
+    n = 6000
+    a = np.concatenate([rng.normal(-1.0, 0.4, n // 2), rng.normal(1.2, 0.6, n - n // 2)])
+    b = np.concatenate([rng.normal(0.5, 0.3, n // 2), rng.normal(-0.8, 0.5, n - n // 2)])
+    a[:3] = [9.0, -8.0, 7.5]                                # outliers: cut by the 1 % / 99 % crop
+    phi = rng.vonmises(-1.2, 3.0, n)
+    psi = rng.vonmises(2.4, 1.5, n)
+    cases = {
+        "adaptive": (a, b, dict(bins=(40, 40))),
+        "fixed": (a, b, dict(bins=(30, 50), grid_strategy="fixed", min_count=2)),
+        "ranges": (a, b, dict(bins=(25, 25), ranges=((-2.0, 2.5), (-2.0, 1.5)), grid_strategy="fixed", temperature=330.0)),
+        "torus": (phi, psi, dict(bins=(36, 36), periodic=(True, True), grid_strategy="fixed")),
+        "half_torus": (phi, b, dict(bins=(20, 20), periodic=(True, False))),
+        "auto": (a, b, dict(bins=(40, 40), fes_smoothing_mode="auto")),
+        "always": (a, b, dict(bins=(40, 40), grid_strategy="fixed", config={"fes_smoothing_mode": "always", "fes_h0": 0.9})),
+    }
+    out = dict(a=a, b=b, phi=phi, psi=psi)
+    for name, (u, v, kw) in cases.items():
+        r = generate_2d_fes(u, v, **kw)
+        md = r.metadata
+        out.update({f"{name}_F": r.F, f"{name}_xedges": r.xedges, f"{name}_yedges": r.yedges,
+                    f"{name}_density": md["counts"], f"{name}_mask": md["mask"],
+                    f"{name}_shape": np.asarray(md["grid_shape"]), f"{name}_empty": np.float64(md["empty_bins_fraction"]),
+                    f"{name}_applied": np.float64(md["smoothing"]["applied_fraction"])})
+    np.savez_compressed(OUT / "fes2d.npz", **out)
+
+
 if __name__ == "__main__":
+    golden_fes2d()
     golden_debug()
     golden_free_energy()
     golden_validate()
