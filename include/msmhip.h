@@ -504,6 +504,10 @@ msm_status msm_kde2d(msm_ctx* ctx, const double* d_x, int64_t sx, const double* 
 msm_status msm_clip_or_wrap(msm_ctx* ctx, const double* d_x, int64_t stride, int64_t n, double lo, double hi, int mode,
                             double* d_out);
 
+/* d_out[t] = d_table[d_idx[t]], 0 for an index outside [0, m): the frame weights pi[state] of the MSM-reweighted
+ * free-energy surface (FESCalculator.calculate_fes, S/markov_state_model/free_energy.py:1011). */
+msm_status msm_gather_f64(msm_ctx* ctx, const double* d_table, int m, const int32_t* d_idx, int64_t n, double* d_out);
+
 /* ---- dense solves on T: committors, reactive flux, lumping, MFPT ---------------------------
  * msm_solve_f64: A X = B by Gaussian elimination with partial pivoting (first maximal pivot),
  *   one workgroup; d_A [n, lda] is overwritten by the factors, d_B [n, ldb] by X.

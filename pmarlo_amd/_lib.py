@@ -89,6 +89,7 @@ _PROTOTYPES: dict[str, tuple] = {
     "msm_philox4x32": (_i32, [_vp, C.c_uint64, _vp, _vp]),
     "msm_gemm_f64": (_i32, [_vp, _i32, _i32, _i32, _vp, _i64, _vp, _i64, _vp, _i64]),
     "msm_diff_norms": (_i32, [_vp, _vp, _i64, _vp, _i64, _i32, _i32, _vp]),
+    "msm_gather_f64": (_i32, [_vp, _vp, _i32, _vp, _i64, _vp]),
     "msm_clip_or_wrap": (_i32, [_vp, _vp, _i64, _i64, _f64, _f64, _i32, _vp]),
     "msm_order_statistics": (_i32, [_vp, _vp, _i64, _i64, _vp, _i32, _vp]),
     "msm_weighted_stats": (_i32, [_vp, _vp, _i64, _i64, _vp, _vp]),

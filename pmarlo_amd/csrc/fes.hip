@@ -318,6 +318,15 @@ __global__ void kde_reduce_kernel(const double* __restrict__ slabs, int n_slabs,
 }  // namespace
 
 namespace {
+// out[t] = table[idx[t]] (0 for an index outside [0, m)): per-frame weights pi[state] of the MSM-reweighted FES
+__global__ __launch_bounds__(256) void gather_kernel(const double* __restrict__ table, int m, const int32_t* __restrict__ idx,
+                                                     int64_t n, double* __restrict__ out) {
+    for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < n; t += (int64_t)gridDim.x * 256) {
+        const int i = idx[t];
+        out[t] = (unsigned)i < (unsigned)m ? table[i] : 0.0;
+    }
+}
+
 // mode 1: np.clip(x, lo, hi);  mode 2: ((x - lo) % (hi - lo)) + lo with numpy's remainder (result in [lo, hi))
 __global__ __launch_bounds__(256) void clip_or_wrap_kernel(const double* __restrict__ x, int64_t stride, int64_t n,
                                                            double lo, double hi, int mode, double* __restrict__ out) {
@@ -454,6 +463,16 @@ msm_status msm_clip_or_wrap(msm_ctx* ctx, const double* d_x, int64_t stride, int
     if (n == 0) return MSM_OK;
     const int blocks = (int)std::min<int64_t>(std::max<int64_t>(1, (n + 1023) / 1024), (int64_t)ctx->n_cu * 8);
     hipLaunchKernelGGL(clip_or_wrap_kernel, dim3(blocks), dim3(256), 0, ctx->stream, d_x, stride, n, lo, hi, mode, d_out);
+    MSM_CHECK_LAUNCH(ctx);
+    return MSM_OK;
+}
+
+msm_status msm_gather_f64(msm_ctx* ctx, const double* d_table, int m, const int32_t* d_idx, int64_t n, double* d_out) {
+    if (!ctx) return MSM_ERR_INVALID;
+    MSM_REQUIRE(ctx, d_table && d_idx && d_out && m >= 1 && n >= 0, "msm_gather_f64: bad arguments");
+    if (n == 0) return MSM_OK;
+    const int blocks = (int)std::min<int64_t>(std::max<int64_t>(1, (n + 1023) / 1024), (int64_t)ctx->n_cu * 8);
+    hipLaunchKernelGGL(gather_kernel, dim3(blocks), dim3(256), 0, ctx->stream, d_table, m, d_idx, n, d_out);
     MSM_CHECK_LAUNCH(ctx);
     return MSM_OK;
 }

@@ -612,6 +612,12 @@ class Engine:
                                      out.ptr), self.handle)
         return out.to_host()
 
+    def gather(self, table: DeviceArray, idx: DeviceArray) -> DeviceArray:
+        """table[idx] for int32 indices (0 where the index is out of range)."""
+        out = self.empty((idx.size,), np.float64)
+        check(lib.msm_gather_f64(self.handle, table.ptr, table.size, idx.ptr, idx.size, out.ptr), self.handle)
+        return out
+
     def hist2d_xy(self, x, y, xedges: np.ndarray, yedges: np.ndarray) -> DeviceArray:
         """np.histogram2d (unweighted) of two device columns on the given edges -> f64 [nx, ny].  x and y are
         (array, column) pairs for columns of 2-D arrays, or 1-D arrays."""

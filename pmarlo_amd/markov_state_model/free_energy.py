@@ -17,7 +17,7 @@ import numpy as np
 
 from ..device import get_engine
 
-__all__ = ["PMFResult", "FESResult", "kT_kJ_per_mol", "free_energy_from_density", "periodic_kde_2d", "generate_1d_pmf",
+__all__ = ["PMFResult", "FESResult", "FESCalculator", "kT_kJ_per_mol", "free_energy_from_density", "periodic_kde_2d", "generate_1d_pmf",
            "generate_2d_fes"]
 
 
@@ -362,3 +362,61 @@ def generate_2d_fes(cv1, cv2, bins: Tuple[int, int] = (100, 100), temperature: f
         metadata["sparse_warning"] = (f"Sparse FES: {empty_fraction * 100.0:.1f}% empty bins detected. "
                                       f"Grid: {bx}\u00d7{by}. Consider using grid_strategy='adaptive' to reduce waste.")
     return FESResult(F=F, xedges=xedges, yedges=yedges, metadata=metadata)
+
+
+class FESCalculator:
+    """MSM-reweighted free-energy surface in kT units (free_energy.py:867-1060): every frame of the projected
+    trajectories is weighted by the stationary probability of its microstate, the weighted density histogram
+    (np.histogram2d(..., weights, density=True) over the data range) becomes -ln(density), shifted to zero and
+    optionally capped.  Weights gather, range and histogram run on the device."""
+
+    def __init__(self, config: dict):
+        self.config = config
+        self.temperature = config.get("temperature", 300.0)
+        self.kbt = 0.00831446261815324 * self.temperature
+
+    def calculate_fes(self, projection, msm, dtrajs=None, bins: int = 150, max_energy_cap_kt: Optional[float] = 10.0,
+                      dim_x: int = 0, dim_y: int = 1):
+        """-> ([xx, yy] bin-centre meshgrids, F in kT), or (None, None) when the inputs do not fit together."""
+        if not projection or msm is None or not hasattr(msm, "stationary_distribution"):
+            return None, None
+        if dtrajs is None:
+            dtrajs = getattr(msm, "discrete_trajectories", None)
+            if dtrajs is None:
+                dtrajs = getattr(msm, "_dtrajs", None)
+            if dtrajs is None:
+                return None, None
+        if isinstance(dtrajs, np.ndarray):
+            dtrajs = [dtrajs]
+        try:
+            labels = np.concatenate([np.asarray(d, dtype=int).reshape(-1) for d in dtrajs])
+            if projection[0].shape[1] <= max(dim_x, dim_y):
+                return None, None
+            xy = np.ascontiguousarray(np.concatenate([np.asarray(p, dtype=np.float64)[:, [dim_x, dim_y]] for p in projection]))
+            pi_raw = getattr(msm, "stationary_distribution", None)
+            if pi_raw is None:
+                return None, None
+            pi = np.asarray(pi_raw, dtype=float)
+            if pi.size == 0 or xy.shape[0] != labels.size:
+                return None, None
+            if labels.max() >= pi.size:                       # frames of states the model does not know are dropped
+                keep = labels < pi.size
+                xy, labels = np.ascontiguousarray(xy[keep]), labels[keep]
+                if labels.size == 0:
+                    return None, None
+            eng = get_engine()
+            xd = eng.to_device(xy)
+            w = eng.gather(eng.to_device(pi), eng.to_device(labels.astype(np.int32)))
+            sx, sy = eng.weighted_stats(xd, 0), eng.weighted_stats(xd, 1)
+            xe = np.linspace(float(sx[4]), float(sx[5]), int(bins) + 1)
+            ye = np.linspace(float(sy[4]), float(sy[5]), int(bins) + 1)
+            hist = eng.hist2d(xd, (0, 1), xe, ye, weights=w, w_absmax=float(pi.max())).to_host()
+            hist = hist / hist.sum() / np.outer(np.diff(xe), np.diff(ye))          # density=True
+            xx, yy = np.meshgrid(0.5 * (xe[:-1] + xe[1:]), 0.5 * (ye[:-1] + ye[1:]))
+            F = -self.kbt * np.log(np.maximum(hist, np.finfo(hist.dtype).tiny))
+            F = (F - F.min()) / self.kbt
+            if max_energy_cap_kt is not None:
+                F = np.clip(F, 0, max_energy_cap_kt)
+            return [xx, yy], F
+        except Exception:
+            return None, None

@@ -523,7 +523,27 @@ def golden_fes2d():
     np.savez_compressed(OUT / "fes2d.npz", **out)
 
 
+def golden_fes_calculator():
+    """free_energy.FESCalculator.calculate_fes: MSM-reweighted FES in kT (weights = pi[microstate])."""
+    from pmarlo.markov_state_model.free_energy import FESCalculator
+
+    rng = np.random.default_rng(53)
+    k = 12
+    pi = rng.dirichlet(np.ones(k) * 2.0)
+    proj = [rng.normal(size=(3000, 3)) * [1.0, 0.5, 2.0], rng.normal(size=(2000, 3)) + [1.5, -0.5, 0.0]]
+    dtr = [rng.integers(0, k, 3000), rng.integers(0, k + 2, 2000)]        # two labels beyond pi: filtered
+    msm = SimpleNamespace(stationary_distribution=pi)
+    calc = FESCalculator({"temperature": 310.0})
+    out = dict(pi=pi, proj0=proj[0], proj1=proj[1], d0=dtr[0], d1=dtr[1])
+    for name, kw in (("default", dict(bins=40)), ("dims", dict(bins=25, dim_x=2, dim_y=0, max_energy_cap_kt=None)),
+                     ("cap", dict(bins=30, max_energy_cap_kt=3.0))):
+        grid, F = calc.calculate_fes(proj, msm, dtrajs=dtr, **kw)
+        out.update({f"{name}_xx": grid[0], f"{name}_yy": grid[1], f"{name}_F": F})
+    np.savez_compressed(OUT / "fes_calculator.npz", **out)
+
+
 if __name__ == "__main__":
+    golden_fes_calculator()
     golden_fes2d()
     golden_debug()
     golden_free_energy()

@@ -213,3 +213,28 @@ def test_generate_2d_fes_crop_path_when_scipy_masks(golden, monkeypatch):
     H, _, _ = np.histogram2d(np.clip(a, *qa), np.clip(b, *qb), bins=(np.linspace(*qa, bx + 1), np.linspace(*qb, by + 1)))
     np.testing.assert_allclose(r.metadata["counts"], H / (H.sum() * np.diff(r.xedges)[0] * np.diff(r.yedges)[0]), rtol=1e-13)
     assert H.sum() == a.size                                   # clipping keeps every sample on the grid
+
+
+def test_fes_calculator_vs_reference_golden(golden):
+    """FESCalculator.calculate_fes (MSM-reweighted FES in kT): device gather of pi[state], data range, weighted
+    histogram; golden made by importing the reference.  Fixed-point weighted sums: 1e-11 on F."""
+    from types import SimpleNamespace
+
+    from pmarlo_amd.markov_state_model.free_energy import FESCalculator
+
+    g = golden("fes_calculator.npz")
+    proj, dtr = [g["proj0"], g["proj1"]], [g["d0"], g["d1"]]
+    msm = SimpleNamespace(stationary_distribution=g["pi"])
+    calc = FESCalculator({"temperature": 310.0})
+    for name, kw in (("default", dict(bins=40)), ("dims", dict(bins=25, dim_x=2, dim_y=0, max_energy_cap_kt=None)),
+                     ("cap", dict(bins=30, max_energy_cap_kt=3.0))):
+        grid, F = calc.calculate_fes(proj, msm, dtrajs=dtr, **kw)
+        np.testing.assert_allclose(grid[0], g[f"{name}_xx"], rtol=1e-14, atol=1e-14)
+        np.testing.assert_allclose(grid[1], g[f"{name}_yy"], rtol=1e-14, atol=1e-14)
+        np.testing.assert_allclose(F, g[f"{name}_F"], rtol=1e-11, atol=1e-11)
+    assert calc.calculate_fes([], msm, dtrajs=dtr) == (None, None)
+    assert calc.calculate_fes(proj, None, dtrajs=dtr) == (None, None)
+    assert calc.calculate_fes(proj, msm, dtrajs=[dtr[0]]) == (None, None)              # frame counts differ
+    assert calc.calculate_fes(proj, msm, dtrajs=dtr, dim_x=5) == (None, None)
+    with_attr = SimpleNamespace(stationary_distribution=g["pi"], discrete_trajectories=dtr)
+    assert calc.calculate_fes(proj, with_attr, bins=10)[1].shape == (10, 10)
