@@ -542,7 +542,32 @@ def golden_fes_calculator():
     np.savez_compressed(OUT / "fes_calculator.npz", **out)
 
 
+def golden_msm_fes():
+    """markov_state_model/_fes.FESMixin numerics called as unbound methods on a stand-in object (the module
+    imports without deeptime; _map_stationary_to_frame_weights then takes its pi[state] fall-back)."""
+    from pmarlo.markov_state_model._fes import FESMixin
+
+    rng = np.random.default_rng(61)
+    k = 9
+    pi = rng.dirichlet(np.ones(k))
+    dtr = [rng.integers(0, k, 5000), rng.integers(0, k, 2500)]
+    obj = SimpleNamespace(dtrajs=dtr, stationary_distribution=pi, lag_time=3)
+    w = FESMixin._map_stationary_to_frame_weights(obj)
+    phi = rng.vonmises(-1.0, 2.0, w.size) * 180.0 / np.pi
+    psi = rng.vonmises(2.0, 1.0, w.size) * 180.0 / np.pi
+    u = rng.normal(size=w.size) * 2.0
+    v = rng.normal(size=w.size) + 0.3 * u
+    out = dict(pi=pi, d0=dtr[0], d1=dtr[1], weights=w, phi=phi, psi=psi, u=u, v=v,
+               bins=np.asarray([FESMixin._choose_bins(obj, t, b) for t, b in ((0, 30), (7500, 50), (7500, 44), (10 ** 6, 10), (90000, 58))]))
+    for name, (a, b, ranges, per) in {"torsion": (phi, psi, [(-180.0, 180.0), (-180.0, 180.0)], True), "plain": (u, v, None, False)}.items():
+        nb = FESMixin._choose_bins(obj, w.size, 50)
+        H, xe, ye = FESMixin._compute_weighted_histogram(obj, a, b, w, nb, ranges, smooth_sigma=0.6, periodic=per)
+        out.update({f"{name}_H": H, f"{name}_xe": xe, f"{name}_ye": ye, f"{name}_F": FESMixin._histogram_to_free_energy(obj, H, 300.0)})
+    np.savez_compressed(OUT / "msm_fes.npz", **out)
+
+
 if __name__ == "__main__":
+    golden_msm_fes()
     golden_fes_calculator()
     golden_fes2d()
     golden_debug()

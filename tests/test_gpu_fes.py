@@ -238,3 +238,30 @@ def test_fes_calculator_vs_reference_golden(golden):
     assert calc.calculate_fes(proj, msm, dtrajs=dtr, dim_x=5) == (None, None)
     with_attr = SimpleNamespace(stationary_distribution=g["pi"], discrete_trajectories=dtr)
     assert calc.calculate_fes(proj, with_attr, bins=10)[1].shape == (10, 10)
+
+
+def test_msm_reweighted_fes_vs_reference_mixin_golden(golden):
+    """markov_state_model/fes.py against FESMixin's methods (golden made by calling them on a stand-in object):
+    frame weights pi[state], bin choice, weighted density histogram with wrap / reflect smoothing, free energy."""
+    from pmarlo_amd.markov_state_model.fes import (choose_bins, generate_free_energy_surface, histogram_to_free_energy,
+                                                    stationary_frame_weights, weighted_density_histogram)
+
+    g = golden("msm_fes.npz")
+    dtr = [g["d0"], g["d1"]]
+    w = stationary_frame_weights(dtr, g["pi"])
+    np.testing.assert_array_equal(w, g["weights"])
+    assert [choose_bins(t, b) for t, b in ((0, 30), (7500, 50), (7500, 44), (10 ** 6, 10), (90000, 58))] == g["bins"].tolist()
+    for name, a, b, ranges, per in (("torsion", g["phi"], g["psi"], [(-180.0, 180.0), (-180.0, 180.0)], True),
+                                    ("plain", g["u"], g["v"], None, False)):
+        H, xe, ye = weighted_density_histogram(a, b, w, choose_bins(w.size, 50), ranges, smooth_sigma=0.6, periodic=per)
+        np.testing.assert_allclose(xe, g[f"{name}_xe"], rtol=1e-14, atol=1e-13)
+        np.testing.assert_allclose(ye, g[f"{name}_ye"], rtol=1e-14, atol=1e-13)
+        np.testing.assert_allclose(H, g[f"{name}_H"], rtol=1e-11, atol=1e-300)
+        np.testing.assert_allclose(histogram_to_free_energy(H, 300.0), g[f"{name}_F"], rtol=1e-10, atol=1e-10)
+    res = generate_free_energy_surface(g["phi"], g["psi"], dtr, g["pi"])
+    np.testing.assert_allclose(res["free_energy"], g["torsion_F"], rtol=1e-10, atol=1e-10)
+    assert res["cv1_name"] == "phi" and res["xedges"][0] == -180.0 and res["temperature"] == 300.0
+    with pytest.raises(ValueError, match="too sparse"):
+        histogram_to_free_energy(np.zeros((3, 3)), 300.0)
+    with pytest.raises(ValueError, match="Could not generate histogram"):
+        weighted_density_histogram([1.0], [1.0, 2.0], [1.0], 40)
