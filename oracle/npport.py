@@ -1132,3 +1132,53 @@ def pmf_1d(cv, bins=100, temperature=300.0, periodic=False, range_=None, smoothi
     if smoothing_sigma and smoothing_sigma > 0:
         H = gaussian_filter(H, sigma=float(smoothing_sigma), mode="wrap" if periodic else "reflect")
     return free_energy_from_density(H, temperature), edges, H
+
+
+# ---- CKMixin (S/markov_state_model/_ck.py:61-358) -------------------------------------------------
+def ck_mixin_micro(dtrajs, n_states, lag, factors=(2, 3, 4, 5), max_states=50, min_transitions=5):
+    from scipy.sparse.csgraph import connected_components
+
+    def count_T(trajs, n, lg):
+        C = _pair_counts(trajs, n, lg)
+        rs = C.sum(1)
+        rs[rs == 0] = 1.0
+        return C / rs[:, None], C
+
+    out = {"mse": {}, "insufficient": False}
+    _, C = count_T(dtrajs, n_states, lag)
+    _, lab = connected_components(((C + C.T) > 0).astype(int), directed=False, return_labels=True)
+    idx = np.where(lab == np.argmax(np.bincount(lab)))[0]
+    if idx.size > max_states:
+        idx = idx[np.argsort((C + C.T).sum(1)[idx])[::-1]][:max_states]
+    lut = -np.ones(n_states, dtype=np.int64)
+    lut[idx] = np.arange(idx.size)
+    trajs = [lut[np.asarray(t)][lut[np.asarray(t)] >= 0] for t in dtrajs]
+    T1, C1 = count_T(trajs, idx.size, lag)
+    if np.any(C1.sum(1) < min_transitions):
+        out["insufficient"] = True
+        return out
+    for f in factors:
+        Te, Ck = count_T(trajs, idx.size, lag * f)
+        if np.any(Ck.sum(1) < min_transitions):
+            out["insufficient"] = True
+            return out
+        d = np.linalg.matrix_power(T1, f) - Te
+        out["mse"][f] = float(np.mean(d * d))
+    return out
+
+
+def ck_mixin_select_lag(dtrajs, n_states, taus, factor=2):
+    def T_of(lg):
+        C = _pair_counts(dtrajs, n_states, lg)
+        rs = C.sum(1)
+        rs[rs == 0] = 1.0
+        return C / rs[:, None]
+
+    mses = []
+    for t in taus:
+        d = np.linalg.matrix_power(T_of(t), factor) - T_of(t * factor)
+        mses.append(float(np.mean(d * d)))
+    best = taus[int(np.nanargmin(mses))]
+    if best == 1 and 2 in taus and mses[taus.index(2)] <= min(mses) + 1e-12:
+        best = 2
+    return best, mses

@@ -16,7 +16,8 @@ import numpy as np
 
 from ..device import get_engine
 
-__all__ = ["CKRunResult", "run_ck"]
+__all__ = ["CKRunResult", "run_ck", "CKTestResult", "compute_ck_test_micro", "compute_ck_test_macrostates",
+           "select_lag_time_ck"]
 
 
 @dataclass
@@ -158,3 +159,137 @@ def run_ck(dtrajs: Sequence[np.ndarray], lag_time: int, macro_k: int = 4, min_tr
         res.mode = "micro"
         res.selected_states = active[top]
     return res
+
+
+# ---- CKMixin (S/markov_state_model/_ck.py:61-228, helpers :258-358) as functions on label sequences -----------------
+@dataclass
+class CKTestResult:
+    mse: Dict[int, float] = field(default_factory=dict)
+    mode: str = "micro"
+    insufficient_data: bool = False
+    thresholds: Dict[str, int] = field(default_factory=dict)
+
+    def to_dict(self):
+        return {"mse": {int(k): float(v) for k, v in self.mse.items()}, "mode": self.mode,
+                "insufficient_data": self.insufficient_data, "thresholds": self.thresholds}
+
+
+def _factors(factors) -> List[int]:
+    return [2, 3, 4, 5] if factors is None else [int(f) for f in factors if int(f) > 1]
+
+
+def _ck_mse_chain(eng, trajs, n_sel: int, lag_time: int, factors: List[int], min_transitions: int, res: CKTestResult) -> None:
+    """mse[f] for the factors in order; the first lag multiple with a row below min_transitions marks the result
+    as insufficient and ends the scan (compute_ck_test_micro :93-108, _macrostates :143-154)."""
+    lags = [lag_time] + [lag_time * f for f in factors]
+    Cd = _device_counts(eng, trajs, n_sel, lags)
+    if Cd is None:
+        res.insufficient_data = True
+        return
+    nn = n_sel * n_sel
+    rows = [eng.transition_matrix(Cd.view((n_sel, n_sel), np.int64, offset_elems=i * nn), mode=0) for i in range(len(lags))]
+    rowsums = np.stack([r["rowsum"].to_host() for r in rows])
+    if np.any(rowsums[0] < min_transitions):
+        res.insufficient_data = True
+        return
+    good = 0
+    while good < len(factors) and not np.any(rowsums[1 + good] < min_transitions):
+        good += 1
+    if good:
+        Tk = eng.empty((good, n_sel, n_sel), np.float64)
+        for j in range(good):
+            Tk.view((n_sel, n_sel), np.float64, offset_elems=j * nn).copy_from(rows[1 + j]["T"])
+        mse, _ = eng.ck_test(rows[0]["T"], Tk, factors[:good])
+        for j in range(good):
+            res.mse[factors[j]] = float(mse[j])
+    if good < len(factors):
+        res.insufficient_data = True
+
+
+def compute_ck_test_micro(dtrajs: Sequence[np.ndarray], n_states: int, lag_time: int, factors=None, max_states: int = 50,
+                          min_transitions: int = 5) -> CKTestResult:
+    """CK test on the largest connected set of microstates (undirected count graph at lag_time), capped to the
+    `max_states` most visited; frames of other states are dropped from the sequences."""
+    from scipy.sparse.csgraph import connected_components
+
+    factors = _factors(factors)
+    res = CKTestResult(mode="micro", thresholds={"min_transitions_per_state": int(min_transitions), "max_states": int(max_states)})
+    if not dtrajs or n_states <= 1 or lag_time <= 0:
+        res.insufficient_data = True
+        return res
+    eng = get_engine()
+    c = _device_counts(eng, dtrajs, int(n_states), [int(lag_time)])
+    if c is None:
+        res.insufficient_data = True
+        return res
+    C = c.to_host()[0].astype(float)
+    _, lab = connected_components(((C + C.T) > 0).astype(int), directed=False, return_labels=True)
+    idx = np.where(lab == int(np.argmax(np.bincount(lab))))[0]
+    if idx.size > max_states:
+        tot = (C + C.T).sum(axis=1)
+        idx = idx[np.argsort(tot[idx])[::-1]][:max_states]
+    if idx.size == 0:
+        res.insufficient_data = True
+        return res
+    _ck_mse_chain(eng, _relabel(dtrajs, idx, int(n_states)), int(idx.size), int(lag_time), factors, int(min_transitions), res)
+    return res
+
+
+def compute_ck_test_macrostates(dtrajs: Sequence[np.ndarray], n_states: int, lag_time: int, macro_labels,
+                                factors=None, min_transitions: int = 5, transition_matrix=None) -> CKTestResult:
+    """CK test on macrostate trajectories (micro label -> macro_labels[label]); needs an eigenvalue gap
+    lambda_2 - lambda_3 > 0.01 of the microstate matrix (`transition_matrix`, or the row-normalised lag counts)."""
+    factors = _factors(factors)
+    eng = get_engine()
+    if transition_matrix is not None:
+        Td = eng.to_device(np.ascontiguousarray(transition_matrix, dtype=np.float64))
+    else:
+        c = _device_counts(eng, dtrajs, int(n_states), [int(lag_time)]) if dtrajs and n_states > 0 and lag_time > 0 else None
+        Td = None if c is None else eng.transition_matrix(c.view((int(n_states), int(n_states)), np.int64), mode=0)["T"]
+    gap = None
+    if Td is not None and Td.shape[0] > 2:
+        spec = eng.spectrum(Td, n_its=0, n_watch=3, want_pi=False, allow_unconverged=True)
+        ev = np.sort(np.real(spec["ritz"][0][:min(Td.shape[0], spec["p"])]))[::-1]
+        gap = float(ev[1] - ev[2])
+    if gap is None or gap <= 0.01:
+        raise RuntimeError("Insufficient spectral gap for macrostate CK test")
+    res = CKTestResult(mode="macro", thresholds={"min_transitions_per_state": int(min_transitions)})
+    if not dtrajs or n_states <= 0 or lag_time <= 0:
+        res.insufficient_data = True
+        return res
+    if macro_labels is None:
+        raise RuntimeError("Macrostate labels are required for macrostate CK test")
+    macro = np.asarray(macro_labels, dtype=np.int64)
+    n_macro = int(macro.max() + 1)
+    if n_macro <= 1:
+        raise RuntimeError("Macrostate CK test requires at least two macrostates")
+    mtraj = [macro[np.asarray(t, dtype=np.int64)].astype(np.int32) for t in dtrajs]
+    _ck_mse_chain(eng, mtraj, n_macro, int(lag_time), factors, int(min_transitions), res)
+    return res
+
+
+def select_lag_time_ck(dtrajs: Sequence[np.ndarray], n_states: int, tau_candidates: Sequence[int], factor: int = 2,
+                       mse_epsilon: float = 0.05) -> int:
+    """The candidate with the smallest CK error mean((T(tau)^factor - T(factor tau))^2) over all microstates, tau = 2
+    preferred over tau = 1 on a tie (select_lag_time_ck :157-171: the prefix rule it evaluates first is
+    overwritten by the best-MSE rule, which is kept).  Counts for every tau and factor * tau come from one
+    lag-scan pass."""
+    taus = [int(t) for t in tau_candidates]
+    if not taus:
+        raise ValueError("no lag candidates")
+    eng = get_engine()
+    k = int(n_states)
+    lags = sorted({t for t in taus} | {t * int(factor) for t in taus})
+    Cd = _device_counts(eng, dtrajs, k, lags)
+    if Cd is None:
+        raise ValueError("no frames")
+    where = {lv: i for i, lv in enumerate(lags)}
+    T = {lv: eng.transition_matrix(Cd.view((k, k), np.int64, offset_elems=where[lv] * k * k), mode=0)["T"] for lv in lags}
+    mses = []
+    for t in taus:
+        mse, _ = eng.ck_test(T[t], T[t * int(factor)].view((1, k, k)), [int(factor)])
+        mses.append(float(mse[0]))
+    best = taus[int(np.nanargmin(mses))]
+    if best == 1 and 2 in taus and mses[taus.index(2)] <= mses[int(np.nanargmin(mses))] + 1e-12:
+        best = 2
+    return int(best)

@@ -125,3 +125,42 @@ def test_run_ck_macro_branch_on_reversible_counts():
     assert run_ck([x], 3, macro_k=4, min_trans=50, factors=(2,)).mode == "micro"
     # more macrostates than the spectrum supports: the gap test (< 0.01 is rare here) or PCCA+ decides; k <= macro_k skips
     assert run_ck(dtrajs, 3, macro_k=40, min_trans=50, factors=(2,)).mode == "micro"
+
+
+def test_ck_mixin_functions_vs_oracle():
+    """compute_ck_test_micro / _macrostates / select_lag_time_ck (CKMixin, S/markov_state_model/_ck.py; the module
+    needs mdtraj to import: numpy restatement as the checker)."""
+    from pmarlo_amd.markov_state_model.ck import compute_ck_test_macrostates, compute_ck_test_micro, select_lag_time_ck
+
+    dtrajs = _markov_dtrajs(30, 40_000, seed=9)
+    n_states = int(max(t.max() for t in dtrajs)) + 1
+    for max_states in (50, 12):
+        want = npport.ck_mixin_micro(dtrajs, n_states, 2, factors=(2, 3, 4), max_states=max_states, min_transitions=5)
+        got = compute_ck_test_micro(dtrajs, n_states, 2, factors=[2, 3, 4], max_states=max_states, min_transitions=5)
+        assert got.mode == "micro" and got.insufficient_data == want["insufficient"] and sorted(got.mse) == sorted(want["mse"])
+        for f, v in want["mse"].items():
+            np.testing.assert_allclose(got.mse[f], v, rtol=1e-10)
+    short = [t[:1500] for t in dtrajs]
+    seen_insufficient = False
+    for min_tr in (20, 60, 90, 200):                    # somewhere along this ladder a factor runs out of counts
+        thin = compute_ck_test_micro(short, n_states, 2, factors=[2, 400, 3], min_transitions=min_tr)
+        want = npport.ck_mixin_micro(short, n_states, 2, factors=(2, 400, 3), min_transitions=min_tr)
+        assert thin.insufficient_data == want["insufficient"] and sorted(thin.mse) == sorted(want["mse"])
+        seen_insufficient |= thin.insufficient_data
+    assert seen_insufficient
+    assert compute_ck_test_micro([], 5, 1).insufficient_data
+    # macrostates: 5-state blocks of the generator -> labels by block
+    macro = np.concatenate([[0, 0, 0], np.arange(30) // 5])           # ids 0..2 unused by trajectory 1, shifted in 0
+    got = compute_ck_test_macrostates(dtrajs, n_states, 2, macro, factors=[2, 3])
+    mt = [macro[t] for t in dtrajs]
+    want = npport.ck_mixin_micro(mt, int(macro.max()) + 1, 2, factors=(2, 3), max_states=10 ** 6, min_transitions=5)
+    assert got.mode == "macro" and not got.insufficient_data
+    for f, v in want["mse"].items():
+        np.testing.assert_allclose(got.mse[f], v, rtol=1e-10)
+    with pytest.raises(RuntimeError, match="labels are required"):
+        compute_ck_test_macrostates(dtrajs, n_states, 2, None)
+    with pytest.raises(RuntimeError, match="spectral gap"):
+        compute_ck_test_macrostates(dtrajs, n_states, 2, macro, transition_matrix=np.full((4, 4), 0.25))
+    taus = [1, 2, 3, 5, 8]
+    best, mses = npport.ck_mixin_select_lag(dtrajs, n_states, taus, factor=2)
+    assert select_lag_time_ck(dtrajs, n_states, taus, factor=2) == best
