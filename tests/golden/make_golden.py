@@ -4,6 +4,9 @@ Run in the build container only (the reference tree does not travel):
 
     PYTHONPATH=/root/reference/src python tests/golden/make_golden.py
 
+Re-running reproduces every committed array exactly, except the scikit-learn k-means centres
+(discretize.npz `centers`, kmeans.npz `ar_centers`), which come back within one ulp (threaded sums).
+
 Every array written here is either an input (seeded synthetic data, or
 coordinates parsed from the reference's data/*.pdb) or the output of a reference
 function on that input.  No reference source text is stored.  The functions
