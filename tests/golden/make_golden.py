@@ -569,7 +569,24 @@ def golden_msm_fes():
     np.savez_compressed(OUT / "msm_fes.npz", **out)
 
 
+def golden_fes_smoothing():
+    """markov_state_model/fes_smoothing.py on a seeded count grid."""
+    from pmarlo.markov_state_model import fes_smoothing as fs
+
+    rng = np.random.default_rng(71)
+    counts = rng.poisson(rng.gamma(0.6, 8.0, size=(24, 31))).astype(float)
+    F = rng.normal(size=counts.shape) * 3.0 + 5.0
+    mask, sd = fs.mark_bins_for_smoothing(counts, target_sd_kT=0.5, alpha=1e-6, kT=2.5)
+    h = fs.adaptive_bandwidth(counts, h0=1.2, ess_ref=50.0, h_min=0.4, h_max=3.0)
+    out = dict(counts=counts, F=F, mask=mask, sd=sd, h=h, smooth_all=fs.smooth_F_with_adaptive_gaussian(F, h),
+               smooth_masked=fs.smooth_F_with_adaptive_gaussian(F, h, apply_mask=mask),
+               smooth_grid=fs.smooth_F_with_adaptive_gaussian(F, h, sigma_grid=(0.3, 0.9, 2.5)),
+               sd_default=fs.fes_uncertainty_sd_kT(counts))
+    np.savez_compressed(OUT / "fes_smoothing.npz", **out)
+
+
 if __name__ == "__main__":
+    golden_fes_smoothing()
     golden_msm_fes()
     golden_fes_calculator()
     golden_fes2d()

@@ -1,0 +1,70 @@
+"""Host-side logic of the free-energy shims that needs no device: grid-level arithmetic and the rank rules
+that turn quantile requests into order statistics.  Goldens were made by importing the reference
+(tests/golden/make_golden.py); the rank rules are checked against scipy / numpy themselves."""
+import numpy as np
+import pytest
+from scipy.stats.mstats import mquantiles
+
+
+def test_fes_smoothing_vs_reference_golden(golden):
+    from pmarlo_amd.markov_state_model import fes_smoothing as fs
+
+    g = golden("fes_smoothing.npz")
+    mask, sd = fs.mark_bins_for_smoothing(g["counts"], target_sd_kT=0.5, alpha=1e-6, kT=2.5)
+    np.testing.assert_array_equal(mask, g["mask"])
+    np.testing.assert_allclose(sd, g["sd"], rtol=1e-14)
+    np.testing.assert_allclose(fs.fes_uncertainty_sd_kT(g["counts"]), g["sd_default"], rtol=1e-14)
+    h = fs.adaptive_bandwidth(g["counts"], h0=1.2, ess_ref=50.0, h_min=0.4, h_max=3.0)
+    np.testing.assert_array_equal(h, g["h"])
+    np.testing.assert_allclose(fs.smooth_F_with_adaptive_gaussian(g["F"], h), g["smooth_all"], rtol=1e-13, atol=1e-13)
+    np.testing.assert_allclose(fs.smooth_F_with_adaptive_gaussian(g["F"], h, apply_mask=mask), g["smooth_masked"],
+                               rtol=1e-13, atol=1e-13)
+    np.testing.assert_allclose(fs.smooth_F_with_adaptive_gaussian(g["F"], h, sigma_grid=(0.3, 0.9, 2.5)), g["smooth_grid"],
+                               rtol=1e-13, atol=1e-13)
+    assert fs.beta_to_kT(0.4) == 2.5
+    with pytest.raises(ValueError):
+        fs.beta_to_kT(0.0)
+    with pytest.raises(ValueError):
+        fs.fes_uncertainty_sd_kT(np.array([1.0, -1.0]))
+    with pytest.raises(ValueError):
+        fs.smooth_F_with_adaptive_gaussian(np.zeros((2, 2)), np.zeros((3, 2)))
+
+
+def test_free_energy_from_density_and_mixin_helpers_golden(golden):
+    from pmarlo_amd.markov_state_model.fes import choose_bins, histogram_to_free_energy
+    from pmarlo_amd.markov_state_model.free_energy import FESResult, free_energy_from_density, kT_kJ_per_mol
+
+    g = golden("free_energy.npz")
+    d, m = g["dens"], g["mask"]
+    for name, kw in (("F_plain", dict(temperature=300.0)), ("F_mask", dict(temperature=310.0, mask=m)),
+                     ("F_inpaint", dict(temperature=310.0, mask=m, inpaint=True)), ("F_tiny", dict(temperature=300.0, tiny=0.01))):
+        np.testing.assert_allclose(free_energy_from_density(d, **kw), g[name], rtol=1e-13, atol=1e-12, equal_nan=True)
+    assert kT_kJ_per_mol(300.0) == pytest.approx(2.494338785, rel=1e-9)
+    f = golden("msm_fes.npz")
+    assert [choose_bins(t, b) for t, b in ((0, 30), (7500, 50), (7500, 44), (10 ** 6, 10), (90000, 58))] == f["bins"].tolist()
+    for name in ("torsion", "plain"):
+        np.testing.assert_allclose(histogram_to_free_energy(f[f"{name}_H"], 300.0), f[f"{name}_F"], rtol=1e-13, atol=1e-12)
+    r = FESResult(free_energy=np.zeros((3, 4)), xedges=np.arange(4), yedges=np.arange(5), metadata={"temperature": 310, "counts": np.ones((3, 4))})
+    assert r.output_shape == (3, 4) and r.temperature == 310.0 and r.counts.shape == (3, 4) and r.metadata["temperature"] == 310.0
+    with pytest.raises(TypeError):
+        FESResult(xedges=[0, 1], yedges=[0, 1])
+
+
+@pytest.mark.parametrize("n", [2, 3, 10, 101, 1000, 4097])
+def test_rank_rules_reproduce_scipy_and_numpy_quantiles(n):
+    """_mquantile_pair / _percentile_pair: which order statistics a quantile needs and how they are blended
+    (the device supplies the order statistics; here they come from a sort)."""
+    from pmarlo_amd.markov_state_model.free_energy import _mquantile_pair, _percentile_pair
+
+    rng = np.random.default_rng(n)
+    x = rng.normal(size=n) * 3.0
+    xs = np.sort(x)
+    for p in (0.01, 0.25, 0.5, 0.99):
+        lo, hi, g = _mquantile_pair(n, p)
+        assert (1.0 - g) * xs[lo] + g * xs[hi] == pytest.approx(float(mquantiles(x, prob=[p])[0]), rel=1e-15, abs=1e-15)
+    for pct in (25.0, 50.0, 75.0, 1.0, 99.0):
+        lo, hi, tag = _percentile_pair(n, pct)
+        t = -tag - 1.0
+        a, b = xs[lo], xs[hi]
+        got = a + (b - a) * t if t < 0.5 else b - (b - a) * (1.0 - t)
+        assert got == pytest.approx(float(np.percentile(x, pct)), rel=1e-15, abs=1e-15)
