@@ -68,3 +68,38 @@ def test_rank_rules_reproduce_scipy_and_numpy_quantiles(n):
         a, b = xs[lo], xs[hi]
         got = a + (b - a) * t if t < 0.5 else b - (b - a) * (1.0 - t)
         assert got == pytest.approx(float(np.percentile(x, pct)), rel=1e-15, abs=1e-15)
+
+
+def test_graph_and_selection_helpers():
+    """Pure host pieces of the lag selector, the TPT pathway search, PCCA+ and the debug export."""
+    from pmarlo_amd.analysis.debug_export import _valid_segment_lengths, analyse_scc, compute_component_coverage
+    from pmarlo_amd.markov_state_model.ck_its_selector import _auto_macrostates, _coverage_fraction, _median_count
+    from pmarlo_amd.markov_state_model.pcca import _complete, _inner_simplex
+    from pmarlo_amd.markov_state_model.tpt import _widest_path
+
+    C = np.array([[5, 1, 0, 0], [2, 7, 0, 0], [0, 0, 3, 1], [0, 0, 0, 0.0]])
+    assert _coverage_fraction(C) == 0.5 and _median_count(C) == int(np.median([13, 17, 7, 1]))
+    assert _coverage_fraction(np.zeros((0, 0))) == 0.0 and _median_count(np.zeros((3, 3))) == 0
+    ev = np.array([1.0, 0.97, 0.95, 0.5, 0.45, 0.1, 0.05])
+    assert _auto_macrostates(ev, 2, 6) == 3                      # largest gap: between the third and fourth
+    assert _auto_macrostates(ev[:2], 2, 6) == 2
+    s = analyse_scc(C)
+    assert sorted(len(c) for c in s.components) == [1, 1, 2] and s.largest_component.tolist() == [0, 1]
+    assert compute_component_coverage(np.array([10, 10, 5, 0]), [0, 1]) == 0.8
+    assert compute_component_coverage(np.zeros(3), [0]) is None
+    assert _valid_segment_lengths([np.array([0, 1, -1, -1, 2, 2, 2]), np.array([-1]), np.array([], int), np.array([4, 4])]) == [2, 3, 2]
+    # widest path: the bottleneck-maximising route, ties to the lower index
+    F = np.zeros((5, 5))
+    F[0, 1], F[1, 4], F[0, 2], F[2, 4], F[0, 3], F[3, 4] = 3.0, 1.0, 2.0, 2.0, 2.0, 2.0
+    assert _widest_path(F, 0, 4) == ([0, 2, 4], 2.0)
+    assert _widest_path(F, 4, 0) == (None, 0.0)
+    # inner simplex: three well separated clusters in eigenvector space -> one vertex from each
+    rng = np.random.default_rng(0)
+    base = np.array([[1.0, 1.0, 0.0], [1.0, -0.5, 1.0], [1.0, -0.5, -1.0]])
+    R = np.repeat(base, 20, axis=0) + rng.normal(scale=1e-3, size=(60, 3)) * [0, 1, 1]
+    A = _inner_simplex(R)
+    chi = R @ A
+    np.testing.assert_allclose(chi.sum(1), 1.0, atol=1e-9)
+    assert sorted(np.argmax(chi, axis=1)[::20].tolist()) == [0, 1, 2]
+    A2 = _complete(A[1:, 1:], R)                                  # feasible completion: memberships >= 0, columns of A sum
+    assert (R @ A2).min() >= -1e-12 and np.allclose((R @ A2).sum(1), 1.0, atol=1e-9)
