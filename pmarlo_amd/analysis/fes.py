@@ -4,8 +4,8 @@
 passes on the GPU: column variances, weighted statistics, the 2-D histogram (LDS bins, integer
 atomics) and the Gaussian KDE (fp64 matrix cores, frames as the contraction index).
 
-Not mirrored: ``apply_whitening`` from DeepTICA metadata (ensure_fes_inputs_whitened, :295-380) --
-pass whitened CVs and ``apply_whitening=False``, or a dataset without ``mlcv_deeptica`` artifacts."""
+``apply_whitening`` from DeepTICA metadata (ensure_fes_inputs_whitened, :295-380) runs through
+analysis/project_cv.py (device projection / moment passes)."""
 
 from __future__ import annotations
 
@@ -95,6 +95,47 @@ def _bandwidth(var: float, ess: float, selector) -> float:
     return bw
 
 
+def ensure_fes_inputs_whitened(dataset) -> bool:
+    """Apply the DeepTICA output whitening recorded under dataset["__artifacts__"]["mlcv_deeptica"] to the
+    top-level "X" and then to every split's "X" (S/analysis/fes.py:295-380).  False when there is nothing to
+    apply (no artifacts, no metadata, no top-level X, or metadata without a transform)."""
+    from .project_cv import apply_whitening_from_metadata
+
+    if not isinstance(dataset, (MutableMapping, dict)):
+        raise TypeError("Dataset must be a mutable mapping to apply whitening")
+    artifacts = dataset.get("__artifacts__")
+    if artifacts is None:
+        return False
+    if not isinstance(artifacts, Mapping):
+        raise ValueError(f"Dataset __artifacts__ must be a Mapping, got {type(artifacts)}")
+    summary = artifacts.get("mlcv_deeptica")
+    if summary is None or "X" not in dataset:
+        return False
+    if dataset["X"] is None:
+        raise ValueError("Dataset provides no coordinate array for whitening")
+    if not isinstance(summary, (MutableMapping, dict)):
+        raise ValueError(f"mlcv_deeptica metadata must be a dict, got {type(summary)}")
+    if summary.get("output_mean") is None or summary.get("output_transform") is None:
+        return False
+    whitened, applied = apply_whitening_from_metadata(np.asarray(dataset["X"], dtype=np.float64), summary)
+    dataset["X"] = whitened
+    applied_any = bool(applied)
+    if applied:
+        splits = dataset.get("splits")
+        if isinstance(splits, Mapping):
+            for name, data in splits.items():
+                if not isinstance(data, MutableMapping) or "X" not in data:
+                    continue
+                if data["X"] is None:
+                    raise ValueError(f"Split '{name}' provides no coordinate array for whitening")
+                summary["output_transform_applied"] = False           # every split takes the transform once
+                out, did = apply_whitening_from_metadata(np.asarray(data["X"], dtype=np.float64), summary)
+                data["X"] = out
+                applied_any = applied_any or bool(did)
+            summary["output_transform_applied"] = True
+    return applied_any
+
+
 def compute_weighted_fes(dataset, *, split: str | None = None, weights=None, bins=64, temperature_K: float = 300.0,
                          method: str = "kde", bandwidth: str | float = "scott", min_count_per_bin: int = 1,
                          apply_whitening: bool = True) -> dict[str, Any]:
@@ -102,10 +143,8 @@ def compute_weighted_fes(dataset, *, split: str | None = None, weights=None, bin
     of the split; ``method`` "kde" (Gaussian product kernel on the bin centres) or "grid"."""
     if not isinstance(dataset, (MutableMapping, dict)):
         raise ValueError("Dataset must be a mapping with 'splits'")
-    art = dataset.get("__artifacts__")
-    if apply_whitening and isinstance(art, Mapping) and isinstance(art.get("mlcv_deeptica"), Mapping):
-        raise NotImplementedError("DeepTICA output whitening (ensure_fes_inputs_whitened) is outside the accelerated "
-                                  "path; whiten the CVs and pass apply_whitening=False")
+    if apply_whitening:
+        ensure_fes_inputs_whitened(dataset)
     split_name, split_data = _select_split(dataset, split)
     if "X" not in split_data:
         raise KeyError("Split is missing 'X'")

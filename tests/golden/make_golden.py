@@ -585,7 +585,35 @@ def golden_fes_smoothing():
     np.savez_compressed(OUT / "fes_smoothing.npz", **out)
 
 
+def golden_whitening():
+    """analysis/project_cv.apply_whitening_from_metadata (ml/deeptica/whitening.apply_output_transform) and
+    analysis/fes.ensure_fes_inputs_whitened + compute_weighted_fes on a dataset with DeepTICA artifacts."""
+    from pmarlo.analysis import fes as ref_fes
+    from pmarlo.analysis.project_cv import apply_whitening_from_metadata
+
+    rng = np.random.default_rng(83)
+    n, d = 4000, 3
+    A = rng.normal(size=(d, d))
+    Y = rng.normal(size=(n, d)) @ A + np.array([2.0, -1.0, 0.5])
+    mean = Y.mean(0) + rng.normal(scale=0.05, size=d)
+    W = np.linalg.inv(np.linalg.cholesky(np.cov(Y.T))).T + rng.normal(scale=0.02, size=(d, d))
+    out = dict(Y=Y, mean=mean, W=W)
+    md = {"output_mean": mean.tolist(), "output_transform": W.tolist(), "output_transform_applied": "false"}
+    out["whitened"], applied = apply_whitening_from_metadata(Y, md)
+    out["applied"] = np.bool_(applied)
+    out["again"], again = apply_whitening_from_metadata(Y, md)            # flag now set: returned unchanged
+    out["again_applied"] = np.bool_(again)
+    out["few"], _ = apply_whitening_from_metadata(Y[:2], {"output_mean": mean, "output_transform": W})   # n <= d: no batch whitening
+    ds = {"X": Y.copy(), "splits": {"train": {"X": Y[:3000].copy()}, "val": {"X": Y[3000:].copy()}},
+          "__artifacts__": {"mlcv_deeptica": {"output_mean": mean.tolist(), "output_transform": W.tolist()}}}
+    res = ref_fes.compute_weighted_fes(ds, split="train", bins=14, method="kde")
+    out.update(fes_F=res["free_energy"], fes_hist=res["histogram"], fes_xedges=res["xedges"], fes_yedges=res["yedges"],
+               ds_X=np.asarray(ds["X"]), ds_train=np.asarray(ds["splits"]["train"]["X"]), ds_val=np.asarray(ds["splits"]["val"]["X"]))
+    np.savez_compressed(OUT / "whitening.npz", **out)
+
+
 if __name__ == "__main__":
+    golden_whitening()
     golden_fes_smoothing()
     golden_msm_fes()
     golden_fes_calculator()

@@ -265,3 +265,37 @@ def test_msm_reweighted_fes_vs_reference_mixin_golden(golden):
         histogram_to_free_energy(np.zeros((3, 3)), 300.0)
     with pytest.raises(ValueError, match="Could not generate histogram"):
         weighted_density_histogram([1.0], [1.0, 2.0], [1.0], 40)
+
+
+def test_output_whitening_vs_reference_golden(golden):
+    """apply_whitening_from_metadata / ensure_fes_inputs_whitened: device projection + moment passes with the
+    d x d algebra on the host; golden made by importing the reference (1e-11: different summation order)."""
+    from pmarlo_amd.analysis.fes import compute_weighted_fes
+    from pmarlo_amd.analysis.project_cv import apply_whitening_from_metadata
+
+    g = golden("whitening.npz")
+    Y, mean, W = g["Y"], g["mean"], g["W"]
+    md = {"output_mean": mean.tolist(), "output_transform": W.tolist(), "output_transform_applied": "false"}
+    out, applied = apply_whitening_from_metadata(Y, md)
+    assert applied == bool(g["applied"]) and md["output_transform_applied"] is True
+    np.testing.assert_allclose(out, g["whitened"], rtol=0, atol=1e-11)
+    # (the reference multiplies by L^-1 rather than L^-T, so the batch covariance comes out near, not at, identity)
+    again, did = apply_whitening_from_metadata(Y, md)
+    assert did == bool(g["again_applied"]) and again is not None
+    np.testing.assert_array_equal(again, g["again"])
+    few, _ = apply_whitening_from_metadata(Y[:2], {"output_mean": mean, "output_transform": W})
+    np.testing.assert_allclose(few, g["few"], rtol=0, atol=1e-12)
+    ds = {"X": Y.copy(), "splits": {"train": {"X": Y[:3000].copy()}, "val": {"X": Y[3000:].copy()}},
+          "__artifacts__": {"mlcv_deeptica": {"output_mean": mean.tolist(), "output_transform": W.tolist()}}}
+    res = compute_weighted_fes(ds, split="train", bins=14, method="kde")
+    np.testing.assert_allclose(ds["X"], g["ds_X"], atol=1e-11)
+    np.testing.assert_allclose(ds["splits"]["train"]["X"], g["ds_train"], atol=1e-11)
+    np.testing.assert_allclose(ds["splits"]["val"]["X"], g["ds_val"], atol=1e-11)
+    np.testing.assert_allclose(res["xedges"], g["fes_xedges"], rtol=1e-10, atol=1e-10)
+    np.testing.assert_allclose(res["histogram"], g["fes_hist"], rtol=1e-8)
+    np.testing.assert_allclose(res["free_energy"], g["fes_F"], atol=1e-7)
+    for bad in ({"output_mean": mean}, None):
+        with pytest.raises((ValueError, TypeError)):
+            apply_whitening_from_metadata(Y, bad)
+    with pytest.raises(ValueError, match="boolean-like"):
+        apply_whitening_from_metadata(Y, {"output_mean": mean, "output_transform": W, "output_transform_applied": "maybe"})
