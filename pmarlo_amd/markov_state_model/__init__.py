@@ -1,7 +1,7 @@
 """pmarlo.markov_state_model operators on the MI355X engine."""
 from .ck import CKRunResult, run_ck  # noqa: F401
 from .clustering import ClusteringResult, cluster_microstates  # noqa: F401
-from .estimation import (build_msm, build_simple_msm, compute_free_energies, count_transitions,  # noqa: F401
+from .estimation import (build_msm, build_simple_msm, check_transition_matrix, compute_free_energies, count_transitions,  # noqa: F401
                          ensure_connected_counts, finalize_transition_and_stationary, fit_reversible_msm)
 from .features import MSMFeatures, ca_distance_pairs, compute_msm_features  # noqa: F401
 from .its import (  # noqa: F401

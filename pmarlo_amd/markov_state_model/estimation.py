@@ -134,9 +134,55 @@ def build_simple_msm(dtrajs: Sequence[np.ndarray], n_states: int | None = None, 
         return np.empty((0, 0), dtype=float), np.empty((0,), dtype=float)
     C = count_transitions(dtrajs, n_states, lag=int(max(1, lag)), count_mode=count_mode)
     T, pi, _ = fit_reversible_msm(C)
-    # check_transition_matrix (S/utils/msm_utils.py): rows sum to one, pi is stationary
-    if not np.allclose(T.sum(axis=1), 1.0, atol=1e-12):
-        raise ValueError("transition matrix rows must sum to 1")
-    if pi.sum() > 0 and not np.allclose(pi @ T, pi, atol=1e-8):
-        raise ValueError("stationary distribution is not invariant under T")
+    check_transition_matrix(T, pi)
     return T, pi
+
+
+def check_transition_matrix(T: np.ndarray, pi: np.ndarray, *, row_tol: float = 1e-12, stat_tol: float = 1e-8) -> None:
+    """Validate a transition matrix with its stationary vector (S/utils/msm_utils.py:168-299): non-negative
+    entries, unit row sums, pi T = pi, and agreement of pi with the stationary vector of T itself (from the device
+    solver) -- except on states the chain cannot reach from the support of pi, which mark T as reducible instead
+    of failing.  Raises ValueError; returns nothing."""
+    from scipy.sparse import csr_matrix
+    from scipy.sparse.csgraph import connected_components
+
+    T = np.asarray(T, dtype=float)
+    pi = np.asarray(pi, dtype=float)
+    if T.ndim != 2 or T.shape[0] != T.shape[1]:
+        raise ValueError("transition matrix must be square")
+    if pi.shape != (T.shape[0],):
+        raise ValueError("stationary distribution size mismatch")
+    if T.size == 0:
+        return
+    if np.any(T < 0.0):
+        raise ValueError("Negative probabilities in transition matrix")
+    if np.abs(T.sum(axis=1) - 1.0).max() >= T.shape[0] * row_tol:       # deeptime's is_transition_matrix(T, tol)
+        raise ValueError("transition matrix fails stochasticity checks")
+    total = float(pi.sum())
+    if not np.isfinite(total) or total <= 0:
+        raise ValueError("stationary distribution must be normalisable")
+    p = pi / total
+    residual = float(np.max(np.abs(p @ T - p)))
+    if residual > stat_tol:
+        raise ValueError(f"provided stationary distribution fails invariance check (max residual {residual})")
+    rate = 1e-6                                                         # constants.NUMERIC_MIN_RATE
+    reducible = False
+    if T.shape[0] > 1:
+        n_comp, lab = connected_components(csr_matrix((T > rate).astype(int)), directed=True, connection="strong")
+        if n_comp > 1:
+            closed = [not np.any((T[lab == c] > rate)[:, lab != c]) for c in range(n_comp)]
+            reducible = sum(closed) > 1
+    eng = get_engine()
+    ref = eng.spectrum(eng.to_device(np.ascontiguousarray(T)), n_its=0, allow_unconverged=True)["pi"].to_host().ravel()
+    diff = np.abs(p - ref)
+    support = p > stat_tol
+    if support.any():
+        unreachable = ~support & ~np.any(T[support] > rate, axis=0)
+    else:
+        unreachable = np.ones(diff.shape, dtype=bool)
+    if unreachable.any():
+        diff[unreachable] = 0.0
+        reducible = True
+    worst = float(diff.max()) if diff.size else 0.0
+    if worst > stat_tol and not reducible:
+        raise ValueError(f"Stationary distribution mismatch at state {int(np.argmax(diff))} with error {worst}")

@@ -100,3 +100,36 @@ def test_large_matrix_timing(engine):
     T = out["T"].to_host()
     np.testing.assert_allclose(T.sum(1), 1.0, rtol=1e-13)
     assert per < 2e-3
+
+
+def test_check_transition_matrix(engine):
+    from pmarlo_amd.markov_state_model import check_transition_matrix
+
+    C = _counts(12, 4)
+    T, pi, _ = fit_reversible_msm(C)
+    check_transition_matrix(T, pi)                                   # a valid pair passes silently
+    check_transition_matrix(T, 5.0 * pi)                             # pi is normalised first
+    with pytest.raises(ValueError, match="invariance"):
+        check_transition_matrix(T, np.roll(pi, 1))
+    bad = T.copy()
+    bad[0, 0] -= 0.2
+    bad[0, 1] += 0.1
+    with pytest.raises(ValueError, match="stochasticity"):
+        check_transition_matrix(bad, pi)
+    neg = T.copy()
+    neg[0, 0], neg[0, 1] = -0.1, T[0, 1] + T[0, 0] + 0.1
+    with pytest.raises(ValueError, match="Negative"):
+        check_transition_matrix(neg, pi)
+    with pytest.raises(ValueError, match="size mismatch"):
+        check_transition_matrix(T, pi[:-1])
+    with pytest.raises(ValueError, match="normalisable"):
+        check_transition_matrix(T, np.zeros_like(pi))
+    # two closed blocks: a vector supported on one block is stationary; the other block is unreachable from it
+    R = np.zeros((6, 6))
+    R[:3, :3] = T[:3, :3] / T[:3, :3].sum(1, keepdims=True)
+    R[3:, 3:] = T[3:6, 3:6] / T[3:6, 3:6].sum(1, keepdims=True)
+    w, v = np.linalg.eig(R[:3, :3].T)
+    p = np.zeros(6)
+    p[:3] = np.real(v[:, np.argmax(np.real(w))])
+    check_transition_matrix(R, p / p.sum())
+    check_transition_matrix(np.empty((0, 0)), np.empty((0,)))
