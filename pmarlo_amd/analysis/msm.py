@@ -1,5 +1,6 @@
 """prepare_msm_discretization: mirror of pmarlo.analysis.msm (S/analysis/msm.py:53-106).
-Like the reference, ``apply_whitening`` is not forwarded to discretize_dataset (:74-82)."""
+``apply_whitening`` whitens the top-level "X" from DeepTICA metadata when present (ensure_msm_inputs_whitened
+:18-50); like the reference it is not forwarded to discretize_dataset (:74-82)."""
 
 from __future__ import annotations
 
@@ -9,7 +10,29 @@ import numpy as np
 
 from .discretize import MSMDiscretizationResult, discretize_dataset
 
-__all__ = ["prepare_msm_discretization"]
+__all__ = ["prepare_msm_discretization", "ensure_msm_inputs_whitened"]
+
+
+def ensure_msm_inputs_whitened(dataset) -> bool:
+    """Whiten dataset["X"] with the DeepTICA output transform recorded under
+    dataset["__artifacts__"]["mlcv_deeptica"], once (S/analysis/msm.py:18-50).  True when it was applied."""
+    from .project_cv import apply_whitening_from_metadata
+
+    if not isinstance(dataset, (MutableMapping, dict)):
+        return False
+    X = dataset.get("X")
+    if X is None:
+        return False
+    artifacts = dataset.get("__artifacts__")
+    summary = artifacts.get("mlcv_deeptica") if isinstance(artifacts, Mapping) else None
+    if not isinstance(summary, Mapping):
+        return False
+    if summary.get("output_mean") is None or summary.get("output_transform") is None:
+        return False
+    whitened, applied = apply_whitening_from_metadata(np.asarray(X, dtype=np.float64), summary)
+    if applied:
+        dataset["X"] = whitened
+    return applied
 
 
 def prepare_msm_discretization(dataset, *, cluster_mode: str = "kmeans", n_microstates: int = 150, lag_time: int = 1,
@@ -17,10 +40,8 @@ def prepare_msm_discretization(dataset, *, cluster_mode: str = "kmeans", n_micro
                                random_state: int | None = None, apply_whitening: bool = True,
                                centers: np.ndarray | None = None) -> MSMDiscretizationResult:
     if isinstance(dataset, (MutableMapping, dict)):
-        art = dataset.get("__artifacts__")
-        if apply_whitening and isinstance(art, Mapping) and isinstance(art.get("mlcv_deeptica"), Mapping):
-            raise NotImplementedError("DeepTICA output whitening (ensure_msm_inputs_whitened) is outside the "
-                                      "accelerated path; whiten the CVs before calling")
+        if apply_whitening:
+            ensure_msm_inputs_whitened(dataset)
         if frame_weights is None and dataset.get("frame_weights") is not None:
             frame_weights = dataset.get("frame_weights")
     result = discretize_dataset(dataset, cluster_mode=cluster_mode, n_microstates=n_microstates, lag_time=lag_time,

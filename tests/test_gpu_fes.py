@@ -299,3 +299,19 @@ def test_output_whitening_vs_reference_golden(golden):
             apply_whitening_from_metadata(Y, bad)
     with pytest.raises(ValueError, match="boolean-like"):
         apply_whitening_from_metadata(Y, {"output_mean": mean, "output_transform": W, "output_transform_applied": "maybe"})
+
+
+def test_ensure_msm_inputs_whitened(golden):
+    """analysis/msm.ensure_msm_inputs_whitened: top-level X whitened once from the DeepTICA metadata."""
+    from pmarlo_amd.analysis.msm import ensure_msm_inputs_whitened
+
+    g = golden("whitening.npz")
+    ds = {"X": g["Y"].copy(), "__artifacts__": {"mlcv_deeptica": {"output_mean": g["mean"].tolist(),
+                                                                   "output_transform": g["W"].tolist()}}}
+    assert ensure_msm_inputs_whitened(ds) is True
+    np.testing.assert_allclose(ds["X"], g["whitened"], atol=1e-11)
+    before = ds["X"].copy()
+    assert ensure_msm_inputs_whitened(ds) is False                    # flag set: not applied twice
+    np.testing.assert_array_equal(ds["X"], before)
+    assert ensure_msm_inputs_whitened({"X": g["Y"]}) is False and ensure_msm_inputs_whitened([1, 2]) is False
+    assert ensure_msm_inputs_whitened({"X": g["Y"], "__artifacts__": {"mlcv_deeptica": {"output_mean": None}}}) is False
