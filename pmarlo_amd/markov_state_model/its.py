@@ -21,11 +21,16 @@ from ..device import get_engine
 from .estimation import _concat_dtrajs
 from .results import ITSResult
 
-__all__ = ["safe_timescales", "compute_implied_timescales", "deterministic_its_from_counts", "detect_timescale_plateau",
+__all__ = ["format_lag_window_ps", "safe_timescales", "compute_implied_timescales", "deterministic_its_from_counts", "detect_timescale_plateau",
            "select_lag_from_its",
            "candidate_lag_ladder", "DEFAULT_ITS_LAGS"]
 
 EPS = 1e-12
+
+
+def format_lag_window_ps(window: tuple[float, float]) -> str:
+    """"start\u2013end ps" with three decimals (S/markov_state_model/utils.py:60-64)."""
+    return f"{window[0]:.3f}\u2013{window[1]:.3f} ps"
 
 
 def safe_timescales(lag: float, eigvals, eps: float = EPS) -> np.ndarray:

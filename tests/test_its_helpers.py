@@ -73,3 +73,9 @@ def test_oracle_philox_known_answers():
             [0xD16CFE09, 0x94FDCCEB, 0x5001E420, 0x24126EA1])]
     for key, ctr, want in kat:
         np.testing.assert_array_equal(npport.philox4x32(key, np.asarray(ctr, np.uint32)), np.asarray(want, np.uint32))
+
+
+def test_format_lag_window_ps():
+    from pmarlo_amd.markov_state_model.its import format_lag_window_ps
+
+    assert format_lag_window_ps((2.0, 10.5)) == "2.000–10.500 ps"
