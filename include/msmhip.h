@@ -339,6 +339,34 @@ msm_status msm_kmeans_accumulate(msm_ctx* ctx, const void* d_x, msm_dtype dtype,
 msm_status msm_kmeans_update(msm_ctx* ctx, int64_t* d_sums, int64_t* d_counts, int k, int d,
                              double* d_centers, double* d_state, int clear);
 
+/* Frame images for the certified bf16 filter (pmarlo_amd/csrc/kmeans_filter.h).  For d <= 10 and a centre
+ * table that fits the LDS (k <= ~750 at d = 10) msm_kmeans_assign / _accumulate / _fit take the labels from a
+ * bf16 matrix-core pass over three-way bf16 splits of the coordinates: an upper bound of every pinned fp64 score,
+ * the winner's candidates re-scored with the pinned fp64 chain and accepted only when they beat every bound
+ * outside the candidate set; the remaining ~1 % of the frames take an exhaustive fp64 scan.  Labels, ties,
+ * distances and member sums are those of the all-fp64 arithmetic stated at msm_kmeans_assign, bit for bit
+ * (same reference lines: S/analysis/discretize.py:471-494, S/markov_state_model/clustering.py:608-609).
+ *
+ * The image of a frame (its split coordinates in matrix-operand order, 64 or 128 bytes) depends only on the
+ * frame and the whitening, so a caller that runs many passes over the same frames (Lloyd iterations) builds
+ * it once with msm_kmeans_pack and hands it to the _packed entry points; the plain entry points build it per
+ * call in a buffer of the context.  d_image == NULL or a shape outside the filter's range: same as the plain
+ * call.  msm_kmeans_image_bytes gives the size (0 for d > 10); the buffer must be 16-byte aligned.
+ * msm_kmeans_filter_scanned reports (and optionally clears) the number of frames that took the exhaustive
+ * scan since the context was created: diagnostics only. */
+msm_status msm_kmeans_image_bytes(int64_t n, int d, size_t* out_bytes);
+msm_status msm_kmeans_pack(msm_ctx* ctx, const void* d_x, msm_dtype dtype, int64_t n, int d, int64_t ld,
+                           const double* d_mean, const double* d_std, void* d_image);
+msm_status msm_kmeans_assign_packed(msm_ctx* ctx, const void* d_x, msm_dtype dtype, int64_t n, int d,
+                                    int64_t ld, const double* d_centers, int k, const double* d_mean,
+                                    const double* d_std, const void* d_image, int32_t* d_labels,
+                                    double* d_mindist);
+msm_status msm_kmeans_accumulate_packed(msm_ctx* ctx, const void* d_x, msm_dtype dtype, int64_t n, int d,
+                                        int64_t ld, const double* d_centers, int k, const double* d_mean,
+                                        const double* d_std, const void* d_image, const double* d_state,
+                                        int64_t* d_sums, int64_t* d_counts);
+msm_status msm_kmeans_filter_scanned(msm_ctx* ctx, uint64_t* h_out, int reset);
+
 /* d_out[0] = sum of d_v[0..n) with a fixed-order two-level reduction (inertia =
  * sum of msm_kmeans_assign's d_mindist; clustering.py:391-392). */
 msm_status msm_sum_f64(msm_ctx* ctx, const double* d_v, int64_t n, double* d_out);

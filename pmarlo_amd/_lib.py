@@ -76,6 +76,11 @@ _PROTOTYPES: dict[str, tuple] = {
         _i32, [_vp, _vp, _i32, _i64, _i32, _i64, _vp, _vp, _i32, C.c_uint64, _i32, _f64, _f64, _vp, _vp, _i32]),
     "msm_kmeans_accumulate": (_i32, [_vp, _vp, _i32, _i64, _i32, _i64, _vp, _i32, _vp, _vp, _vp, _vp, _vp]),
     "msm_kmeans_update": (_i32, [_vp, _vp, _vp, _i32, _i32, _vp, _vp, _i32]),
+    "msm_kmeans_image_bytes": (_i32, [_i64, _i32, C.POINTER(_sz)]),
+    "msm_kmeans_pack": (_i32, [_vp, _vp, _i32, _i64, _i32, _i64, _vp, _vp, _vp]),
+    "msm_kmeans_assign_packed": (_i32, [_vp, _vp, _i32, _i64, _i32, _i64, _vp, _i32, _vp, _vp, _vp, _vp, _vp]),
+    "msm_kmeans_accumulate_packed": (_i32, [_vp, _vp, _i32, _i64, _i32, _i64, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "msm_kmeans_filter_scanned": (_i32, [_vp, C.POINTER(C.c_uint64), _i32]),
     "msm_run_lengths": (_i32, [_vp, _vp, _i64, _i32, _vp, _vp, _vp, _i64, _vp]),
     "msm_sum_f64": (_i32, [_vp, _vp, _i64, _vp]),
     "msm_transition_matrix": (_i32, [_vp, _vp, _i32, _i32, _i32, _f64, _f64, _vp, _vp, _vp, _vp, _vp, _vp]),

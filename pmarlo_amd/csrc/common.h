@@ -25,6 +25,10 @@ struct msm_ctx {
     // (half-norms of the k-means centres during msm_kmeans_fit, whose member sums live in `scratch`)
     void* aux = nullptr;
     size_t aux_bytes = 0;
+    // bf16 frame images of the k-means filter when the caller did not supply one (msm_kmeans_pack)
+    void* km_image = nullptr;
+    size_t km_image_bytes = 0;
+    void* km_stats = nullptr;   // device u64: frames that took the filter's exhaustive scan
     // pinned host staging for small tables (segment lists with > MSM_SEG_INLINE entries)
     void* pinned = nullptr;
     size_t pinned_bytes = 0;
@@ -44,6 +48,7 @@ msm_status msm_fail(msm_ctx* ctx, msm_status st, const char* fmt, ...);
 // Ensure ctx->scratch holds at least `bytes`; fails during capture if growth is needed.
 msm_status msm_reserve_scratch(msm_ctx* ctx, size_t bytes);
 msm_status msm_reserve_aux(msm_ctx* ctx, size_t bytes);
+msm_status msm_reserve_km_image(msm_ctx* ctx, size_t bytes);
 
 #define MSM_HIP(ctx, call)                                                              \
     do {                                                                                \

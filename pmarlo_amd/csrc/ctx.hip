@@ -43,6 +43,19 @@ msm_status msm_reserve_aux(msm_ctx* ctx, size_t bytes) {
     return MSM_OK;
 }
 
+msm_status msm_reserve_km_image(msm_ctx* ctx, size_t bytes) {
+    if (bytes <= ctx->km_image_bytes) return MSM_OK;
+    if (ctx->capturing)
+        return msm_fail(ctx, MSM_ERR_UNSUPPORTED, "k-means frame images must grow to %zu bytes during graph capture", bytes);
+    MSM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (ctx->km_image) MSM_HIP(ctx, hipFree(ctx->km_image));
+    ctx->km_image = nullptr;
+    ctx->km_image_bytes = 0;
+    MSM_HIP(ctx, hipMalloc(&ctx->km_image, bytes));
+    ctx->km_image_bytes = bytes;
+    return MSM_OK;
+}
+
 static msm_status reserve_tables(msm_ctx* ctx, size_t bytes) {
     if (bytes <= ctx->pinned_bytes) return MSM_OK;
     if (ctx->capturing)
@@ -144,6 +157,8 @@ void msm_ctx_destroy(msm_ctx* ctx) {
     (void)hipStreamSynchronize(ctx->stream);
     if (ctx->scratch) (void)hipFree(ctx->scratch);
     if (ctx->aux) (void)hipFree(ctx->aux);
+    if (ctx->km_image) (void)hipFree(ctx->km_image);
+    if (ctx->km_stats) (void)hipFree(ctx->km_stats);
     if (ctx->dtab) (void)hipFree(ctx->dtab);
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);

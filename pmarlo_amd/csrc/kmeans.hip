@@ -14,6 +14,9 @@
 //   argmin with strict '<' over ascending centre index.
 #include "common.h"
 
+#include <algorithm>
+#include <cstdlib>
+
 namespace {
 
 constexpr int kThreads = 256;
@@ -249,13 +252,17 @@ __device__ unsigned long long g_km_stamps[8];
         kacc__[i] += t__ - klast__;                                                        \
         klast__ = t__;                                                                     \
     } while (0)
+#define KSTAMP_VM(i) do { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); KSTAMP(i); } while (0)
 #define KSTAMP_INIT unsigned long long kacc__[8] = {0, 0, 0, 0, 0, 0, 0, 0}; unsigned long long klast__; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(klast__)::"memory");
 #define KSTAMP_FLUSH if (threadIdx.x == 0) { for (int i__ = 0; i__ < 8; ++i__) atomicAdd(&g_km_stamps[i__], kacc__[i__]); }
 #else
 #define KSTAMP(i)
+#define KSTAMP_VM(i)
 #define KSTAMP_INIT
 #define KSTAMP_FLUSH
 #endif
+
+#include "kmeans_filter.h"
 
 // |c_j|^2 / 2 as the ascending-feature FMA chain (multi-chunk launches: once per launch instead of
 // once per workgroup and chunk)
@@ -793,10 +800,118 @@ msm_status launch_mfma(msm_ctx* ctx, const T* x, int64_t n, int d, int64_t ld, c
     return MSM_OK;
 }
 
+// ---- certified bf16 filter path (kmeans_filter.h): d <= 10 and centres + images fit the LDS -------------
+bool filter_enabled() {
+    static const bool on = [] {
+        const char* e = getenv("MSM_KMEANS_FILTER");   // MSM_KMEANS_FILTER=0: all-fp64 kernel everywhere (A/B timing)
+        return !(e && e[0] == '0');
+    }();
+    return on;
+}
+
+int filter_stagger() {
+    static const int v = [] {
+        const char* e = getenv("MSM_KMEANS_STAGGER");   // start offset between the waves of a SIMD, units of 512 cycles
+        return e ? atoi(e) : 4;
+    }();
+    return v;
+}
+
+size_t filter_image_bytes(int64_t n, int d) { return (size_t)n * 64 * filter_nm(d); }
+
+template <typename T>
+msm_status launch_pack(msm_ctx* ctx, const T* x, int64_t n, int d, int64_t ld, const double* mean, const double* stdv,
+                       uint4* image) {
+    const unsigned grid = (unsigned)((n + 255) / 256);
+#define MSM_PACK_CASE(D)                                                                                              \
+    case D:                                                                                                           \
+        hipLaunchKernelGGL((kmeans_pack_kernel<T, D>), dim3(grid), dim3(256), 0, ctx->stream, x, n, ld, mean, stdv, image); \
+        break
+    switch (d) {
+        MSM_PACK_CASE(1); MSM_PACK_CASE(2); MSM_PACK_CASE(3); MSM_PACK_CASE(4); MSM_PACK_CASE(5);
+        MSM_PACK_CASE(6); MSM_PACK_CASE(7); MSM_PACK_CASE(8); MSM_PACK_CASE(9); MSM_PACK_CASE(10);
+        default: return msm_fail(ctx, MSM_ERR_UNSUPPORTED, "k-means frame images need d <= %d (got %d)", kFilterMaxD, d);
+    }
+#undef MSM_PACK_CASE
+    MSM_CHECK_LAUNCH(ctx);
+    return MSM_OK;
+}
+
+msm_status filter_stats_buffer(msm_ctx* ctx, unsigned long long** out) {
+    // one device word counting the frames that took the exhaustive scan (diagnostics, msm_kmeans_filter_scanned)
+    static_assert(sizeof(unsigned long long) == 8, "");
+    if (!ctx->km_stats) {
+        if (ctx->capturing) { *out = nullptr; return MSM_OK; }
+        MSM_HIP(ctx, hipMalloc(&ctx->km_stats, 8));
+        MSM_HIP(ctx, hipMemsetAsync(ctx->km_stats, 0, 8, ctx->stream));
+    }
+    *out = (unsigned long long*)ctx->km_stats;
+    return MSM_OK;
+}
+
+template <typename T, int NM, bool ACCUM>
+msm_status launch_filter_nm(msm_ctx* ctx, const T* x, int64_t n, int d, int64_t ld, const double* centers, int k,
+                            const double* mean, const double* stdv, const uint4* image, int32_t* labels, double* mindist,
+                            const FitState* st, unsigned long long* sums, unsigned long long* counts) {
+    using S = FilterShape<NM>;
+    constexpr int NF = 4;
+    const size_t lds = filter_lds_bytes(k, d, ACCUM);
+    const int k16 = (k + 15) & ~15;
+    const int n_tiles = ((k16 / 16) + 1) & ~1;
+    // staged centre tables: image | fp64 rows | guard flag
+    const size_t img_bytes = (size_t)n_tiles * NM * 1024, cs_bytes = (size_t)n_tiles * 16 * S::D1 * sizeof(double);
+    msm_status rs = msm_reserve_aux(ctx, img_bytes + cs_bytes + 16);
+    if (rs != MSM_OK) return rs;
+    uint4* img_g = (uint4*)ctx->aux;
+    double* cs_g = (double*)((char*)ctx->aux + img_bytes);
+    int* flag = (int*)((char*)ctx->aux + img_bytes + cs_bytes);
+    MSM_HIP(ctx, hipMemsetAsync(flag, 0, sizeof(int), ctx->stream));
+    hipLaunchKernelGGL((kmeans_filter_stage_kernel<NM>), dim3(n_tiles), dim3(64), 0, ctx->stream, centers, k, d, img_g, cs_g,
+                       flag);
+    MSM_CHECK_LAUNCH(ctx);
+    const int64_t n_units = (n + 16 * NF - 1) / (16 * NF);
+    const int grid = (int)std::min<int64_t>((n_units + 15) / 16, (int64_t)ctx->n_cu);
+    unsigned long long* stats = nullptr;
+    rs = filter_stats_buffer(ctx, &stats);
+    if (rs != MSM_OK) return rs;
+    auto kern = mean ? kmeans_filter_kernel<T, NM, NF, ACCUM, true> : kmeans_filter_kernel<T, NM, NF, ACCUM, false>;
+    if (lds > 48 * 1024)
+        MSM_HIP(ctx, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(1024), lds, ctx->stream, x, n, d, ld, k, mean, stdv, image,
+                       (const uint4*)img_g, (const double*)cs_g, (const int*)flag, labels, mindist, st, sums, counts, stats,
+                       filter_stagger());
+    MSM_CHECK_LAUNCH(ctx);
+    return MSM_OK;
+}
+
+template <typename T, bool ACCUM>
+msm_status launch_filter(msm_ctx* ctx, const T* x, int64_t n, int d, int64_t ld, const double* centers, int k,
+                         const double* mean, const double* stdv, const uint4* image, int32_t* labels, double* mindist,
+                         const FitState* st, unsigned long long* sums, unsigned long long* counts) {
+    if (filter_nm(d) == 1)
+        return launch_filter_nm<T, 1, ACCUM>(ctx, x, n, d, ld, centers, k, mean, stdv, image, labels, mindist, st, sums,
+                                             counts);
+    return launch_filter_nm<T, 2, ACCUM>(ctx, x, n, d, ld, centers, k, mean, stdv, image, labels, mindist, st, sums, counts);
+}
+
+bool filter_fits(int k, int d, bool accum) { return filter_enabled() && d <= kFilterMaxD && filter_lds_bytes(k, d, accum) != 0; }
+
+// image: the frames' bf16 images (msm_kmeans_pack) or NULL (built here into the context's buffer)
 template <typename T, bool ACCUM>
 msm_status dispatch_mfma(msm_ctx* ctx, const T* x, int64_t n, int d, int64_t ld, const double* centers, int k,
                          const double* mean, const double* stdv, int32_t* labels, double* mindist, const FitState* st,
-                         unsigned long long* sums, unsigned long long* counts) {
+                         unsigned long long* sums, unsigned long long* counts, const void* image = nullptr) {
+    if (filter_fits(k, d, ACCUM)) {
+        if (!image) {
+            msm_status rs = msm_reserve_km_image(ctx, filter_image_bytes(n, d));
+            if (rs != MSM_OK) return rs;
+            rs = launch_pack<T>(ctx, x, n, d, ld, mean, stdv, (uint4*)ctx->km_image);
+            if (rs != MSM_OK) return rs;
+            image = ctx->km_image;
+        }
+        return launch_filter<T, ACCUM>(ctx, x, n, d, ld, centers, k, mean, stdv, (const uint4*)image, labels, mindist, st,
+                                       sums, counts);
+    }
 #define MSM_MFMA_CASE(KSV) \
     if (d <= 4 * KSV)      \
         return launch_mfma<T, KSV, ACCUM>(ctx, x, n, d, ld, centers, k, mean, stdv, labels, mindist, st, sums, counts)
@@ -820,9 +935,9 @@ msm_status dispatch_mfma(msm_ctx* ctx, const T* x, int64_t n, int d, int64_t ld,
 
 extern "C" {
 
-msm_status msm_kmeans_assign(msm_ctx* ctx, const void* d_x, msm_dtype dtype, int64_t n, int d, int64_t ld,
-                             const double* d_centers, int k, const double* d_mean, const double* d_std,
-                             int32_t* d_labels, double* d_mindist) {
+static msm_status kmeans_assign_impl(msm_ctx* ctx, const void* d_x, msm_dtype dtype, int64_t n, int d, int64_t ld,
+                                     const double* d_centers, int k, const double* d_mean, const double* d_std,
+                                     const void* d_image, int32_t* d_labels, double* d_mindist) {
     if (!ctx) return MSM_ERR_INVALID;
     MSM_REQUIRE(ctx, n >= 0 && d >= 1 && k >= 1, "msm_kmeans_assign: need n >= 0, d >= 1, k >= 1");
     MSM_REQUIRE(ctx, ld >= d, "msm_kmeans_assign: ld (%lld) < d (%d)", (long long)ld, d);
@@ -833,11 +948,52 @@ msm_status msm_kmeans_assign(msm_ctx* ctx, const void* d_x, msm_dtype dtype, int
     MSM_REQUIRE(ctx, d_x && d_centers && d_labels, "msm_kmeans_assign: NULL pointer");
     if (dtype == MSM_F32)
         return dispatch_mfma<float, false>(ctx, (const float*)d_x, n, d, ld, d_centers, k, d_mean, d_std, d_labels,
-                                           d_mindist, nullptr, nullptr, nullptr);
+                                           d_mindist, nullptr, nullptr, nullptr, d_image);
     return dispatch_mfma<double, false>(ctx, (const double*)d_x, n, d, ld, d_centers, k, d_mean, d_std, d_labels,
-                                        d_mindist, nullptr, nullptr, nullptr);
+                                        d_mindist, nullptr, nullptr, nullptr, d_image);
 }
 
+msm_status msm_kmeans_assign(msm_ctx* ctx, const void* d_x, msm_dtype dtype, int64_t n, int d, int64_t ld,
+                             const double* d_centers, int k, const double* d_mean, const double* d_std,
+                             int32_t* d_labels, double* d_mindist) {
+    return kmeans_assign_impl(ctx, d_x, dtype, n, d, ld, d_centers, k, d_mean, d_std, nullptr, d_labels, d_mindist);
+}
+
+msm_status msm_kmeans_assign_packed(msm_ctx* ctx, const void* d_x, msm_dtype dtype, int64_t n, int d, int64_t ld,
+                                    const double* d_centers, int k, const double* d_mean, const double* d_std,
+                                    const void* d_image, int32_t* d_labels, double* d_mindist) {
+    return kmeans_assign_impl(ctx, d_x, dtype, n, d, ld, d_centers, k, d_mean, d_std, d_image, d_labels, d_mindist);
+}
+
+msm_status msm_kmeans_image_bytes(int64_t n, int d, size_t* out_bytes) {
+    if (!out_bytes || n < 0 || d < 1) return MSM_ERR_INVALID;
+    *out_bytes = d <= kFilterMaxD ? filter_image_bytes(n, d) : 0;
+    return MSM_OK;
+}
+
+msm_status msm_kmeans_pack(msm_ctx* ctx, const void* d_x, msm_dtype dtype, int64_t n, int d, int64_t ld,
+                           const double* d_mean, const double* d_std, void* d_image) {
+    if (!ctx) return MSM_ERR_INVALID;
+    MSM_REQUIRE(ctx, n >= 0 && d >= 1 && d <= kFilterMaxD && ld >= d, "msm_kmeans_pack: need 1 <= d <= %d, ld >= d",
+                kFilterMaxD);
+    MSM_REQUIRE(ctx, (d_mean == nullptr) == (d_std == nullptr), "msm_kmeans_pack: mean/std must come together");
+    MSM_REQUIRE(ctx, dtype == MSM_F32 || dtype == MSM_F64, "msm_kmeans_pack: bad dtype");
+    if (n == 0) return MSM_OK;
+    MSM_REQUIRE(ctx, d_x && d_image, "msm_kmeans_pack: NULL pointer");
+    MSM_REQUIRE(ctx, ((uintptr_t)d_image & 15) == 0, "msm_kmeans_pack: the image must be 16-byte aligned");
+    if (dtype == MSM_F32) return launch_pack<float>(ctx, (const float*)d_x, n, d, ld, d_mean, d_std, (uint4*)d_image);
+    return launch_pack<double>(ctx, (const double*)d_x, n, d, ld, d_mean, d_std, (uint4*)d_image);
+}
+
+msm_status msm_kmeans_filter_scanned(msm_ctx* ctx, uint64_t* h_out, int reset) {
+    if (!ctx || !h_out) return MSM_ERR_INVALID;
+    *h_out = 0;
+    if (!ctx->km_stats) return MSM_OK;
+    MSM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    MSM_HIP(ctx, hipMemcpy(h_out, ctx->km_stats, 8, hipMemcpyDeviceToHost));
+    if (reset) MSM_HIP(ctx, hipMemset(ctx->km_stats, 0, 8));
+    return MSM_OK;
+}
 
 msm_status msm_kmeans_fit_begin(msm_ctx* ctx, const void* d_x, msm_dtype dtype, int64_t n, int d, int64_t ld,
                                 const double* d_mean, const double* d_std, int k, uint64_t seed, int init_centers,
@@ -879,9 +1035,9 @@ msm_status msm_kmeans_fit_begin(msm_ctx* ctx, const void* d_x, msm_dtype dtype, 
     return MSM_OK;
 }
 
-msm_status msm_kmeans_accumulate(msm_ctx* ctx, const void* d_x, msm_dtype dtype, int64_t n, int d, int64_t ld,
-                                 const double* d_centers, int k, const double* d_mean, const double* d_std,
-                                 const double* d_state, int64_t* d_sums, int64_t* d_counts) {
+static msm_status kmeans_accumulate_impl(msm_ctx* ctx, const void* d_x, msm_dtype dtype, int64_t n, int d, int64_t ld,
+                                         const double* d_centers, int k, const double* d_mean, const double* d_std,
+                                         const void* d_image, const double* d_state, int64_t* d_sums, int64_t* d_counts) {
     if (!ctx) return MSM_ERR_INVALID;
     MSM_REQUIRE(ctx, n >= 0 && d >= 1 && k >= 1 && ld >= d, "msm_kmeans_accumulate: bad shape");
     MSM_REQUIRE(ctx, (d_mean == nullptr) == (d_std == nullptr), "msm_kmeans_accumulate: mean/std must come together");
@@ -891,10 +1047,25 @@ msm_status msm_kmeans_accumulate(msm_ctx* ctx, const void* d_x, msm_dtype dtype,
     if (dtype == MSM_F32)
         return dispatch_mfma<float, true>(ctx, (const float*)d_x, n, d, ld, d_centers, k, d_mean, d_std, nullptr,
                                           nullptr, (const FitState*)d_state, (unsigned long long*)d_sums,
-                                          (unsigned long long*)d_counts);
+                                          (unsigned long long*)d_counts, d_image);
     return dispatch_mfma<double, true>(ctx, (const double*)d_x, n, d, ld, d_centers, k, d_mean, d_std, nullptr, nullptr,
                                        (const FitState*)d_state, (unsigned long long*)d_sums,
-                                       (unsigned long long*)d_counts);
+                                       (unsigned long long*)d_counts, d_image);
+}
+
+msm_status msm_kmeans_accumulate(msm_ctx* ctx, const void* d_x, msm_dtype dtype, int64_t n, int d, int64_t ld,
+                                 const double* d_centers, int k, const double* d_mean, const double* d_std,
+                                 const double* d_state, int64_t* d_sums, int64_t* d_counts) {
+    return kmeans_accumulate_impl(ctx, d_x, dtype, n, d, ld, d_centers, k, d_mean, d_std, nullptr, d_state, d_sums,
+                                  d_counts);
+}
+
+msm_status msm_kmeans_accumulate_packed(msm_ctx* ctx, const void* d_x, msm_dtype dtype, int64_t n, int d, int64_t ld,
+                                        const double* d_centers, int k, const double* d_mean, const double* d_std,
+                                        const void* d_image, const double* d_state, int64_t* d_sums,
+                                        int64_t* d_counts) {
+    return kmeans_accumulate_impl(ctx, d_x, dtype, n, d, ld, d_centers, k, d_mean, d_std, d_image, d_state, d_sums,
+                                  d_counts);
 }
 
 msm_status msm_kmeans_update(msm_ctx* ctx, int64_t* d_sums, int64_t* d_counts, int k, int d, double* d_centers,
@@ -922,8 +1093,17 @@ msm_status msm_kmeans_fit(msm_ctx* ctx, const void* d_x, msm_dtype dtype, int64_
     int64_t* sums = (int64_t*)ctx->scratch;
     int64_t* counts = sums + (size_t)k * d;
     MSM_HIP(ctx, hipMemsetAsync(sums, 0, acc_bytes, ctx->stream));
+    // the frames' bf16 images are built once and serve every iteration (kmeans_filter.h)
+    const void* image = nullptr;
+    if (max_iter > 0 && filter_fits(k, d, true)) {
+        rs = msm_reserve_km_image(ctx, filter_image_bytes(n, d));
+        if (rs != MSM_OK) return rs;
+        rs = msm_kmeans_pack(ctx, d_x, dtype, n, d, ld, d_mean, d_std, ctx->km_image);
+        if (rs != MSM_OK) return rs;
+        image = ctx->km_image;
+    }
     for (int it = 0; it < max_iter; ++it) {
-        rs = msm_kmeans_accumulate(ctx, d_x, dtype, n, d, ld, d_centers, k, d_mean, d_std, d_state, sums, counts);
+        rs = kmeans_accumulate_impl(ctx, d_x, dtype, n, d, ld, d_centers, k, d_mean, d_std, image, d_state, sums, counts);
         if (rs != MSM_OK) return rs;
         rs = msm_kmeans_update(ctx, sums, counts, k, d, d_centers, d_state, 1);
         if (rs != MSM_OK) return rs;

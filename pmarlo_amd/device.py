@@ -427,7 +427,7 @@ class Engine:
     # -- k-means --------------------------------------------------------------
     def kmeans_assign(self, x: DeviceArray, centers: DeviceArray, *, mean: DeviceArray | None = None,
                       std: DeviceArray | None = None, labels: DeviceArray | None = None,
-                      mindist: DeviceArray | None = None) -> DeviceArray:
+                      mindist: DeviceArray | None = None, image: DeviceArray | None = None) -> DeviceArray:
         n, d = x.shape
         k, dc = centers.shape
         if dc != d:
@@ -435,10 +435,11 @@ class Engine:
         if centers.dtype != np.float64:
             raise TypeError("centres must be float64")
         labels = labels if labels is not None else self.empty((n,), np.int32)
-        check(lib.msm_kmeans_assign(self.handle, x.ptr, _dtype_code(x.dtype), n, d, d, centers.ptr, k,
-                                    mean.ptr if mean is not None else None,
-                                    std.ptr if std is not None else None, labels.ptr,
-                                    mindist.ptr if mindist is not None else None), self.handle)
+        check(lib.msm_kmeans_assign_packed(self.handle, x.ptr, _dtype_code(x.dtype), n, d, d, centers.ptr, k,
+                                           mean.ptr if mean is not None else None,
+                                           std.ptr if std is not None else None,
+                                           image.ptr if image is not None else None, labels.ptr,
+                                           mindist.ptr if mindist is not None else None), self.handle)
         return labels
 
 
@@ -475,13 +476,42 @@ class Engine:
         return centers, state
 
     def kmeans_accumulate(self, x: DeviceArray, centers: DeviceArray, state: DeviceArray, sums: DeviceArray,
-                          counts: DeviceArray, *, mean: DeviceArray | None = None, std: DeviceArray | None = None):
+                          counts: DeviceArray, *, mean: DeviceArray | None = None, std: DeviceArray | None = None,
+                          image: DeviceArray | None = None):
         n, d = x.shape
         k = centers.shape[0]
-        check(lib.msm_kmeans_accumulate(self.handle, x.ptr, _dtype_code(x.dtype), n, d, d, centers.ptr, k,
-                                        mean.ptr if mean is not None else None,
-                                        std.ptr if std is not None else None, state.ptr, sums.ptr, counts.ptr),
-              self.handle)
+        check(lib.msm_kmeans_accumulate_packed(self.handle, x.ptr, _dtype_code(x.dtype), n, d, d, centers.ptr, k,
+                                               mean.ptr if mean is not None else None,
+                                               std.ptr if std is not None else None,
+                                               image.ptr if image is not None else None, state.ptr, sums.ptr,
+                                               counts.ptr), self.handle)
+
+    # -- bf16 frame images of the certified filter (msm_kmeans_pack) -----------------------------------------
+    def kmeans_image_bytes(self, n: int, d: int) -> int:
+        out = C.c_size_t(0)
+        check(lib.msm_kmeans_image_bytes(int(n), int(d), C.byref(out)), self.handle)
+        return int(out.value)
+
+    def kmeans_pack(self, x: DeviceArray, *, mean: DeviceArray | None = None, std: DeviceArray | None = None,
+                    image: DeviceArray | None = None) -> DeviceArray | None:
+        """Frame images for repeated k-means passes over the same frames; None when d is outside the filter's range."""
+        n, d = x.shape
+        nbytes = self.kmeans_image_bytes(n, d)
+        if nbytes == 0:
+            return None
+        image = image if image is not None else self.empty((nbytes,), np.uint8)
+        if image.nbytes < nbytes:
+            raise ValueError(f"image buffer holds {image.nbytes} bytes, {nbytes} needed")
+        check(lib.msm_kmeans_pack(self.handle, x.ptr, _dtype_code(x.dtype), n, d, d,
+                                  mean.ptr if mean is not None else None, std.ptr if std is not None else None,
+                                  image.ptr), self.handle)
+        return image
+
+    def kmeans_filter_scanned(self, reset: bool = False) -> int:
+        """Frames that took the filter's exhaustive fp64 scan since the context was created (diagnostics)."""
+        out = C.c_uint64(0)
+        check(lib.msm_kmeans_filter_scanned(self.handle, C.byref(out), int(reset)), self.handle)
+        return int(out.value)
 
     def kmeans_update(self, sums: DeviceArray, counts: DeviceArray, centers: DeviceArray, state: DeviceArray,
                       clear: bool = True):

@@ -71,14 +71,11 @@ class TorchComm(Comm):
         if buf is None:
             buf = torch.empty((self.world,) + tuple(t.shape), dtype=t.dtype, device=t.device)
             self._gather[name] = buf
-        done = False
+        # the collective form was fixed at construction from the backend name; an exception here is a
+        # real communicator / device failure and propagates (the rank exits non-zero)
         if self._into_tensor:
-            try:
-                self.dist.all_gather_into_tensor(buf, t)        # one RCCL call, no per-rank tensor list
-                done = True
-            except (RuntimeError, NotImplementedError, AttributeError):
-                self._into_tensor = False                       # backend without the fused form (refused up front)
-        if not done:
+            self.dist.all_gather_into_tensor(buf, t)            # one RCCL call, no per-rank tensor list
+        else:
             self.dist.all_gather([buf[r] for r in range(self.world)], t)
         # fixed-order sum over the rank axis: one kernel, no atomics, the same bits on every rank
         torch.sum(buf, dim=0, out=t)
@@ -157,6 +154,10 @@ class ShardedMSM:
         self.diag = eng.empty((1,), np.float64)
         self.km_sums = b["km_acc"].view((k * d,), np.int64)
         self.km_counts = b["km_acc"].view((k,), np.int64, offset_elems=k * d)
+        # bf16 frame images of the k-means filter: built once per step after the projection, read by all Lloyd
+        # passes and the final assignment (None when d / k are outside the filter's range)
+        nbytes = eng.kmeans_image_bytes(n, d)
+        self.km_image = eng.empty((nbytes,), np.uint8) if nbytes else None
         self.accum_events: list = []
         self.time_accum = False
         # one shift vector shared by all shards (row 0 of rank 0's shard) so that the raw
@@ -199,18 +200,21 @@ class ShardedMSM:
             comm.allreduce_min("fit_scale")
             comm.reciprocal("fit_inv_scale", "fit_scale")   # 2^-e: exact, no second collective
         check(lib.msm_memset(eng.handle, b["km_acc"].ptr, 0, b["km_acc"].nbytes), eng.handle)
+        if self.km_image is not None:
+            eng.kmeans_pack(self.Y, image=self.km_image)
         for _ in range(cfg.kmeans_iters):
             if self.time_accum:
                 e0, e1 = eng.event(), eng.event()
                 e0.record()
-            eng.kmeans_accumulate(self.Y, b["centers"], b["fit_state"], self.km_sums, self.km_counts)
+            eng.kmeans_accumulate(self.Y, b["centers"], b["fit_state"], self.km_sums, self.km_counts,
+                                  image=self.km_image)
             if self.time_accum:
                 e1.record()
                 self.accum_events.append((e0, e1))
             if multi:
                 comm.allreduce_sum("km_acc")
             eng.kmeans_update(self.km_sums, self.km_counts, b["centers"], b["fit_state"], clear=True)
-        eng.kmeans_assign(self.Y, b["centers"], labels=self.labels)
+        eng.kmeans_assign(self.Y, b["centers"], labels=self.labels, image=self.km_image)
         # 5. lag-tau counts + row-normalised transition matrix
         eng.count_transitions(self.labels, k, cfg.lag, out=b["counts"].view((k, k)),
                               pairs=b["counts"].view((1,), offset_elems=k * k))
