@@ -509,6 +509,378 @@ __device__ void lower_inverse(const double* G, double* X, int n, int ld) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Symmetric eigensolver for n <= 64 without the ~600 barrier-bound Jacobi rounds:
+//   (1) Householder tridiagonalisation A = Q T Q' with Q accumulated (n - 2 steps, 3 barriers each:
+//       reflector by wave 0, the two matrix-vector products A v and Q v with 8 lanes per row, rank-2 / rank-1
+//       updates by everybody);
+//   (2) all eigenvalues of T at once by multisection on Sturm counts: 4 lanes per eigenvalue, 4 trial points
+//       per round, 27 rounds; the count uses the product recurrence
+//       p_j = (d_j - x) p_{j-1} - e_{j-1}^2 p_{j-2} (one dependent fma per row, no division), rescaled every 8 rows;
+//   (3) one eigenvector of T per lane from the twisted factorisation of T - lambda I (forward and backward
+//       pivots, twist at the smallest |gamma|: Parlett & Dhillon), i.e. one exact inverse-iteration step;
+//   (4) Z = Q X.
+// Eigenvectors of T belonging to eigenvalues closer than ~1e-9 |T| come out of (3) short of orthogonal, and
+// exactly repeated eigenvalues give repeated vectors: X'X is checked and the caller falls back to Jacobi on its
+// copy of A when the defect exceeds `orth_tol` (or a residual |T x - lambda x| is large).
+// ---------------------------------------------------------------------------------------------------
+#ifdef MSM_TRI_STAMPS
+__device__ unsigned long long g_tri_stamps[8];
+#define TSTAMP(i) do { if (threadIdx.x == 0) { unsigned long long t__; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t__)::"memory"); g_tri_stamps[i] += t__ - tlast__; tlast__ = t__; } } while (0)
+#define TSTAMP_INIT unsigned long long tlast__ = 0; if (threadIdx.x == 0) { asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tlast__)::"memory"); }
+#else
+#define TSTAMP(i)
+#define TSTAMP_INIT
+#endif
+constexpr int kTriMax = 64;
+struct TriShared {
+    double d[kTriMax], e[kTriMax], e2[kTriMax], lam[kTriMax], vv[kTriMax], praw[kTriMax], uq[kTriMax];
+    double tau, scale, gl, gu;
+    double red[kEigThreads / 64];
+    int bad;
+};
+
+// 64-lane sum on the VALU (row DPP moves, then the two row swaps of gfx950): every lane gets the total, bit for
+// bit the same in every wave that feeds it the same numbers
+template <int CTRL>
+__device__ __forceinline__ double mov_dpp64(double x) {
+    const long long b = __double_as_longlong(x);
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)b, CTRL, 0xf, 0xf, true);
+    const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), CTRL, 0xf, 0xf, true);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned)lo);
+}
+typedef unsigned tri_v2u32 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ double sum8_dpp(double x) {   // sum over aligned groups of 8 lanes
+    x += mov_dpp64<0xB1>(x);    // quad_perm [1,0,3,2]
+    x += mov_dpp64<0x4E>(x);    // quad_perm [2,3,0,1]
+    x += mov_dpp64<0x141>(x);   // row_half_mirror
+    return x;
+}
+__device__ __forceinline__ double wave_sum_all(double x) {
+    x = sum8_dpp(x);
+    x += mov_dpp64<0x140>(x);   // row_mirror: all 16 lanes of a row hold the row sum
+    {
+        const long long b = __double_as_longlong(x);
+        const tri_v2u32 rl = __builtin_amdgcn_permlane16_swap((unsigned)b, (unsigned)b, false, false);
+        const tri_v2u32 rh = __builtin_amdgcn_permlane16_swap((unsigned)(b >> 32), (unsigned)(b >> 32), false, false);
+        x = __longlong_as_double(((long long)rh[0] << 32) | rl[0]) + __longlong_as_double(((long long)rh[1] << 32) | rl[1]);
+    }
+    {
+        const long long b = __double_as_longlong(x);
+        const tri_v2u32 rl = __builtin_amdgcn_permlane32_swap((unsigned)b, (unsigned)b, false, false);
+        const tri_v2u32 rh = __builtin_amdgcn_permlane32_swap((unsigned)(b >> 32), (unsigned)(b >> 32), false, false);
+        x = __longlong_as_double(((long long)rh[0] << 32) | rl[0]) + __longlong_as_double(((long long)rh[1] << 32) | rl[1]);
+    }
+    return x;
+}
+
+// # eigenvalues of the (scaled) tridiagonal matrix below x.  Rows are taken eight at a time: their d and e^2
+// come out of the LDS in one burst, the recurrence itself is one dependent fma per row.
+__device__ __forceinline__ int sturm_count(const TriShared* ts, int n, double x) {
+    // sign changes of p_0 = 1, p_1, ..., p_n, read off the sign bits (an exact zero counts as positive: it only
+    // occurs when x is an eigenvalue of a leading block, and a bracket spoilt by it fails the residual check)
+    double pp = 1.0, p = ts->d[0] - x;
+    unsigned cnt = (unsigned)(__double_as_longlong(p) >> 63) & 1u;
+    auto row = [&](double dj, double e2j) {
+        const double pn = fma(dj - x, p, -(e2j * pp));
+        cnt += (unsigned)((__double_as_longlong(pn) ^ __double_as_longlong(p)) >> 63) & 1u;
+        pp = p;
+        p = pn;
+    };
+    int j = 1;
+    for (; j + 8 <= n; j += 8) {
+        double dd[8], ee[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { dd[u] = ts->d[j + u]; ee[u] = ts->e2[j + u - 1]; }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) row(dd[u], ee[u]);
+        // keep the pair in range (the matrix is scaled to |T| <= 1, so eight rows cannot leave it)
+        const double m = fmax(fabs(p), fabs(pp));
+        if (m > 0.0) {
+            int ex;
+            (void)frexp(m, &ex);
+            p = ldexp(p, -ex);
+            pp = ldexp(pp, -ex);
+        }
+    }
+    for (; j < n; ++j) row(ts->d[j], ts->e2[j - 1]);
+    return (int)cnt;
+}
+
+// A: symmetric n x n (destroyed; on success its columns hold the eigenvectors, ascending eigenvalues in
+// ts->lam).  Q, X: n x n work matrices (same stride).  Returns false (uniformly) when the result must not be
+// used; the caller then solves its own copy of A by Jacobi.  blockDim.x == 1024.
+__device__ bool tridiag_eigh(double* A, double* Q, double* X, int n, int ld, TriShared* ts, double orth_tol) {
+    const int tid = threadIdx.x, nt = blockDim.x, lane = tid & 63, wave = tid >> 6;
+    if (n == 1) {
+        if (tid == 0) { ts->lam[0] = A[0]; A[0] = 1.0; }
+        __syncthreads();
+        return true;
+    }
+    TSTAMP_INIT
+    for (int i = tid; i < n * n; i += nt) Q[(i / n) * ld + (i % n)] = (i / n == i % n) ? 1.0 : 0.0;
+    if (tid == 0) ts->bad = 0;
+    __syncthreads();
+    TSTAMP(0);
+    // ---- (1) tridiagonalisation.  Two barriers per column: every wave forms the reflector itself (same inputs,
+    // same instructions, hence the same bits; all of them write the one copy of v), the products A v and Q v take 8
+    // lanes per row, and the updates have a fixed owner: thread (r0 = tid / 64, c = tid % 64) holds rows r0 + 16 q.
+    const int own_c = lane, own_r0 = wave;
+    for (int k = 0; k + 2 < n; ++k) {
+        const int m = n - k - 1;
+        const double xi = lane < m ? A[(k + 1 + lane) * ld + k] : 0.0;
+        const double sigma = wave_sum_all(lane >= 1 ? xi * xi : 0.0);
+        const double alpha = __shfl(xi, 0, 64);
+        double tau = 0.0, beta = alpha, scal = 0.0;
+        if (sigma != 0.0) {   // uniform
+            const double h2 = fma(alpha, alpha, sigma);
+            const double rs = nr_rsqrt(h2);
+            beta = -copysign(h2 * rs, alpha);
+            tau = (beta - alpha) * -copysign(rs, alpha);   // (beta - alpha) / beta
+            scal = nr_rcp(alpha - beta);
+        }
+        const double vl = lane < m ? (lane == 0 ? 1.0 : xi * scal) : 0.0;
+        ts->vv[lane] = vl;   // lane < 64 = kTriMax: the tail is zero
+        if (tid == 0) { ts->e[k] = beta; ts->d[k] = A[k * ld + k]; }
+        TSTAMP(1);
+        if (tau != 0.0) {   // uniform
+            {   // p_raw = A22 v (rows 0 .. m-1), u = Q[:, k+1:] v (rows m .. m+n-1): 8 lanes per row
+                const int row = tid >> 3, part = tid & 7;
+                const double* src = row < m ? A + (k + 1 + row) * ld + k + 1 : Q + (row < m + n ? row - m : 0) * ld + k + 1;
+                double acc = 0.0;
+                if (row < m + n)
+                    for (int c = part; c < m; c += 8) acc = fma(src[c], ts->vv[c], acc);
+                acc = sum8_dpp(acc);
+                if (part == 0) {
+                    if (row < m) ts->praw[row] = acc;
+                    else if (row < m + n) ts->uq[row - m] = acc;
+                }
+            }
+            __syncthreads();
+            TSTAMP(2);
+            // w = tau p_raw + al v with al = -tau/2 (tau p_raw . v)
+            const double pv = wave_sum_all(lane < m ? ts->praw[lane] * vl : 0.0);
+            const double al = -0.5 * tau * (tau * pv);
+            const int j = own_c - (k + 1);
+            const bool col_in = j >= 0 && own_c < n;
+            const double vj = col_in ? ts->vv[j] : 0.0;
+            const double wj = col_in ? fma(tau, ts->praw[j], al * vj) : 0.0;
+#pragma unroll
+            for (int q4 = 0; q4 < 4; ++q4) {
+                const int r = own_r0 + 16 * q4;
+                const int i = r - (k + 1);
+                if (col_in && r < n) {
+                    if (i >= 0) {
+                        const double vi = ts->vv[i];
+                        const double wi = fma(tau, ts->praw[i], al * vi);
+                        double* a = A + r * ld + own_c;
+                        *a = *a - (vi * wj + wi * vj);
+                    }
+                    double* qq = Q + r * ld + own_c;
+                    *qq = fma(-tau * ts->uq[r], vj, *qq);
+                }
+            }
+        }
+        __syncthreads();
+        TSTAMP(3);
+    }
+    if (tid == 0) {
+        if (n >= 2) { ts->d[n - 2] = A[(n - 2) * ld + n - 2]; ts->e[n - 2] = A[(n - 1) * ld + n - 2]; }
+        ts->d[n - 1] = A[(n - 1) * ld + n - 1];
+        ts->e[n - 1] = 0.0;
+    }
+    __syncthreads();
+    {   // scale to |T| <= 1 by a power of two (exact), Gershgorin bounds of the scaled matrix: wave-parallel
+        const double dl = lane < n ? ts->d[lane] : 0.0, el = lane < n ? ts->e[lane] : 0.0;
+        double an = fmax(fabs(dl), fabs(el));
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) an = fmax(an, __shfl_xor(an, off, 64));
+        double sc = 1.0;
+        if (an > 0.0 && an < 1e300) { int ex; (void)frexp(an, &ex); sc = ldexp(1.0, -ex); }
+        const double ds = dl * sc, es = el * sc;
+        const double em = lane > 0 && lane < n ? fabs(ts->e[lane - 1]) * sc : 0.0;
+        const double rad = em + (lane + 1 < n ? fabs(es) : 0.0);
+        double gl = lane < n ? ds - rad : 1e300, gu = lane < n ? ds + rad : -1e300;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            gl = fmin(gl, __shfl_xor(gl, off, 64));
+            gu = fmax(gu, __shfl_xor(gu, off, 64));
+        }
+        __syncthreads();   // every wave has read the unscaled d, e
+        if (wave == 0) {
+            if (lane < n) { ts->d[lane] = ds; ts->e[lane] = es; ts->e2[lane] = es * es; }
+            if (lane == 0) {
+                if (!(an < 1e300)) ts->bad = 1;   // NaN / inf input
+                ts->scale = sc;
+                const double bn = fmax(fabs(gl), fabs(gu));
+                const double pad = 4.0 * n * 2.220446049250313e-16 * bn + 1e-290;
+                ts->gl = gl - pad;
+                ts->gu = gu + pad;
+            }
+        }
+    }
+    __syncthreads();
+    TSTAMP(4);
+    if (ts->bad) return false;
+    // ---- (2) eigenvalues: eigenvalue i = tid / 4 is bracketed by 4 lanes (the first four waves, one per SIMD:
+    // the count is bound by instruction issue, so fewer trial points over more rounds cost less).  27 rounds: 5^27 = 2^62.7,
+    // the brackets end at rounding level (24 rounds left 4e-12 of orthogonality defect on a cond-1e4 matrix)
+    if (tid < 4 * kTriMax) {
+        const int i = tid >> 2, t = tid & 3;
+        double lo = ts->gl, hi = ts->gu;
+        const bool live = i < n;
+        for (int it = 0; it < 27; ++it) {
+            const double x = lo + (hi - lo) * ((double)(t + 1) * 0.2);
+            const int c = live ? sturm_count(ts, n, x) : 0;
+            double nlo = c <= i ? x : lo, nhi = c > i ? x : hi;
+            nlo = fmax(nlo, mov_dpp64<0xB1>(nlo)); nhi = fmin(nhi, mov_dpp64<0xB1>(nhi));
+            nlo = fmax(nlo, mov_dpp64<0x4E>(nlo)); nhi = fmin(nhi, mov_dpp64<0x4E>(nhi));
+            lo = nlo;
+            hi = nhi;
+        }
+        if (live && t == 0) ts->lam[i] = 0.5 * (lo + hi);
+    }
+    __syncthreads();
+    TSTAMP(5);
+    // ---- (3) eigenvectors of T, eigenvalue i = lane: wave 0 runs the forward pivots q_j (into X[:, i]), wave 1
+    // the backward pivots r_j (their reciprocals into A[:, i]); gamma_j = q_j - e_j^2 / r_{j+1} is smallest at the
+    // twist k; z_k = 1, z_j = -(e_j / q_j) z_{j+1} above it (wave 0), z_{j+1} = -(e_j / r_{j+1}) z_j below (wave 1)
+    const double tiny = 1e-290;
+    if (wave == 0 && lane < n) {
+        const double lamb = ts->lam[lane];
+        double q = ts->d[0] - lamb;
+        X[lane] = q;
+        for (int j = 1; j < n; ++j) {
+            if (fabs(q) < tiny) q = -tiny;
+            q = fma(-ts->e2[j - 1], nr_rcp(q), ts->d[j] - lamb);
+            X[j * ld + lane] = q;
+        }
+    } else if (wave == 1 && lane < n) {
+        const double lamb = ts->lam[lane];
+        double r = ts->d[n - 1] - lamb;
+        if (fabs(r) < tiny) r = -tiny;
+        double ir = nr_rcp(r);
+        A[(n - 1) * ld + lane] = ir;
+        for (int j = n - 2; j >= 0; --j) {
+            r = fma(-ts->e2[j], ir, ts->d[j] - lamb);
+            if (fabs(r) < tiny) r = -tiny;
+            ir = nr_rcp(r);
+            A[j * ld + lane] = ir;
+        }
+    }
+    __syncthreads();
+    if (wave < 2 && lane < n) {
+        int kk = n - 1;
+        double gbest = fabs(X[(n - 1) * ld + lane]);   // gamma_{n-1} = q_{n-1}
+        for (int j = n - 2; j >= 0; --j) {
+            const double g = fabs(fma(-ts->e2[j], A[(j + 1) * ld + lane], X[j * ld + lane]));
+            if (g <= gbest) { gbest = g; kk = j; }   // ties: the smallest index, in both waves alike
+        }
+        double z = 1.0, nrm2 = 0.0;
+        if (wave == 0) {
+            nrm2 = 1.0;
+            for (int j = kk - 1; j >= 0; --j) {
+                double qq = X[j * ld + lane];
+                if (fabs(qq) < tiny) qq = -tiny;
+                z = -(ts->e[j] * nr_rcp(qq)) * z;
+                X[j * ld + lane] = z;
+                nrm2 = fma(z, z, nrm2);
+            }
+            X[kk * ld + lane] = 1.0;
+            ts->praw[lane] = nrm2;
+        } else {
+            for (int j = kk; j + 1 < n; ++j) {
+                z = -(ts->e[j] * A[(j + 1) * ld + lane]) * z;
+                X[(j + 1) * ld + lane] = z;
+                nrm2 = fma(z, z, nrm2);
+            }
+            ts->uq[lane] = nrm2;
+        }
+    }
+    __syncthreads();
+    if (wave == 0 && lane < n) {
+        // normalise and take the residual |T x - lambda x|_inf in the same pass
+        const double lamb = ts->lam[lane];
+        const double nrm2 = ts->praw[lane] + ts->uq[lane];
+        const bool ok = nrm2 > 0.0 && nrm2 < 1e300;
+        const double inv = nr_rsqrt(ok ? nrm2 : 1.0);
+        double res = 0.0, xm = 0.0, x0 = X[lane] * inv, xp;
+        for (int j = 0; j < n; ++j) {
+            xp = j + 1 < n ? X[(j + 1) * ld + lane] * inv : 0.0;
+            const double tx = fma(ts->d[j] - lamb, x0, (j > 0 ? ts->e[j - 1] * xm : 0.0) + (j + 1 < n ? ts->e[j] * xp : 0.0));
+            res = fmax(res, fabs(tx));
+            X[j * ld + lane] = x0;
+            xm = x0;
+            x0 = xp;
+        }
+        if (!ok || !(res <= 1e-10)) ts->bad = 1;   // scaled matrix: |T| <= 1
+    }
+    __syncthreads();
+    TSTAMP(6);
+    if (ts->bad) return false;
+    // ---- orthogonality of X (clustered / repeated eigenvalues), then (4) Z = Q X into A
+    {
+        double worst = 0.0;
+        for (int e0 = tid; e0 < n * n; e0 += nt) {
+            const int a = e0 / n, b = e0 - a * n;
+            if (b > a) continue;
+            double acc = 0.0;
+            for (int k = 0; k < n; ++k) acc = fma(X[k * ld + a], X[k * ld + b], acc);
+            worst = fmax(worst, fabs(acc - (a == b ? 1.0 : 0.0)));
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) worst = fmax(worst, __shfl_xor(worst, off, 64));
+        if (lane == 0) ts->red[wave] = worst;
+        __syncthreads();
+        worst = 0.0;
+        for (int w = 0; w < nt / 64; ++w) worst = fmax(worst, ts->red[w]);
+        if (!(worst <= orth_tol)) return false;
+    }
+    for (int e0 = tid; e0 < n * n; e0 += nt) {
+        const int r = e0 / n, c = e0 - r * n;
+        double acc = 0.0;
+        for (int k = 0; k < n; ++k) acc = fma(Q[r * ld + k], X[k * ld + c], acc);
+        A[r * ld + c] = acc;
+    }
+    if (tid < n) ts->lam[tid] /= ts->scale;
+    __syncthreads();
+    TSTAMP(7);
+    return true;
+}
+
+// Fused LDL' factorisations and unit-lower inverse, ONE barrier per column:
+//   Mp = Lp Dp Lp'  (positive-definiteness probe only: fails as soon as a pivot is not positive)
+//   Mq = L D L',  X = L^-1  (X must hold the identity on entry)
+// Column j is never touched after step j - 1, so step j reads it (and the pivot) without a barrier of its own:
+// trailing update M[a][b] -= M[a][j] M[b][j] / d_j (lower triangle), X[i][c] -= (M[i][j] / d_j) X[j][c].
+// On success the diagonal of Mq holds D and its strict lower triangle the UNSCALED columns (L[i][j] d_j).
+__device__ bool ldl_inverse_pair(double* Mp, double* Mq, double* X, int n, int ld) {
+    const int tid = threadIdx.x, nt = blockDim.x;
+    for (int j = 0; j < n; ++j) {
+        const double pj = Mp[j * ld + j], qj = Mq[j * ld + j];
+        if (!(pj > 0.0) || !(qj > 0.0)) return false;   // every thread reads the same two numbers
+        const double ip = 1.0 / pj, iq = 1.0 / qj;
+        const int m = n - j - 1;
+        for (int e = tid; e < m * m + m * (j + 1); e += nt) {
+            if (e < m * m) {
+                const int a = e / m, b = e - a * m;
+                if (b <= a) {
+                    const int ra = (j + 1 + a) * ld, rb = (j + 1 + b) * ld;
+                    Mp[ra + j + 1 + b] = fma(-(Mp[ra + j] * ip), Mp[rb + j], Mp[ra + j + 1 + b]);
+                    Mq[ra + j + 1 + b] = fma(-(Mq[ra + j] * iq), Mq[rb + j], Mq[ra + j + 1 + b]);
+                }
+            } else {
+                const int e2 = e - m * m;
+                const int a = e2 / (j + 1), c = e2 - a * (j + 1);
+                const int i = j + 1 + a;
+                X[i * ld + c] = fma(-(Mq[i * ld + j] * iq), X[j * ld + c], X[i * ld + c]);
+            }
+        }
+        __syncthreads();
+    }
+    return true;
+}
+
 struct TicaWork {  // global scratch: four n*ld matrices, then ev[n], mean[n], isc[n], order[n]
     double *A, *V, *B1, *B2, *ev, *mean, *isc;
     int* order;
@@ -553,6 +925,7 @@ __global__ __launch_bounds__(kEigThreads) void tica_solve_kernel(
     int* __restrict__ out_rank) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     __shared__ JacobiShared sh;
+    __shared__ TriShared ts;
     const int tid = threadIdx.x, nt = blockDim.x;
     double* lds = reinterpret_cast<double*>(smem_raw);
     const size_t mat = (size_t)n * ld;
@@ -579,36 +952,72 @@ __global__ __launch_bounds__(kEigThreads) void tica_solve_kernel(
         out_mean[i] = wk.mean[i];
     }
     __syncthreads();
-    for (int e = tid; e < n * n; e += nt) {
-        const int i = e / n, j = e - i * n;
-        const double ss = wk.isc[i] * wk.isc[j];
-        const double mm = wk.mean[i] * wk.mean[j];
-        A[i * ld + j] = 0.5 * (M00[e] + M00[j * n + i]) / w * ss - mm;   // C00
-        B1[i * ld + j] = (M0t[e] + M0t[j * n + i]) / w * ss - mm;        // C0t
-    }
-    __syncthreads();
+    auto build_cov = [&]() {
+        for (int e = tid; e < n * n; e += nt) {
+            const int i = e / n, j = e - i * n;
+            const double ss = wk.isc[i] * wk.isc[j];
+            const double mm = wk.mean[i] * wk.mean[j];
+            A[i * ld + j] = 0.5 * (M00[e] + M00[j * n + i]) / w * ss - mm;   // C00
+            B1[i * ld + j] = (M0t[e] + M0t[j * n + i]) / w * ss - mm;        // C0t
+        }
+        __syncthreads();
+    };
+    build_cov();
 
     // ---- whitening L with L' C00 L = I -------------------------------------------------
     // deeptime's spd_inv_split keeps the eigen-directions of C00 with |s| >= epsilon.  When
-    // ALL of them qualify (C00 - epsilon I positive definite: tested by a Cholesky attempt)
+    // ALL of them qualify (C00 - epsilon I positive definite: tested by a factorisation attempt)
     // the TICA eigenpairs do not depend on which whitening is used -- they solve
-    // C0t r = lambda C00 r -- so L = chol(C00)^-T replaces the first Jacobi eigensolve
-    // (~15x cheaper).  Rank-deficient C00 takes the eigen path below, as before.
-    for (int e = tid; e < n * n; e += nt) {
-        const int i = e / n, j = e - i * n;
-        B2[i * ld + j] = A[i * ld + j] - (i == j ? epsilon : 0.0);
-        V[i * ld + j] = A[i * ld + j];
-    }
-    __syncthreads();
-    const bool full_rank = cholesky_lower_pair(B2, V, n, ld, &sh);   // probe on C00 - eps I, factor C00 = G G'
-    int rank;
-    if (full_rank) {
-        lower_inverse(V, A, n, ld);         // A = G^-1 (lower)
+    // C0t r = lambda C00 r -- so L = chol(C00)^-T replaces the first eigensolve.
+    // Rank-deficient C00 takes the eigen path below, as before.
+    constexpr bool kFused = lds_mats == 4;   // fused LDL' + inverse (one barrier per column) and the tridiagonal solver
+    bool full_rank;
+    if (kFused && n <= kTriMax) {
         for (int e = tid; e < n * n; e += nt) {
             const int i = e / n, j = e - i * n;
-            B2[i * ld + j] = j >= i ? A[j * ld + i] : 0.0;  // L = G^-T (upper)
+            B2[i * ld + j] = A[i * ld + j] - (i == j ? epsilon : 0.0);
+            V[i * ld + j] = A[i * ld + j];
         }
         __syncthreads();
+        for (int e = tid; e < n * n; e += nt) {
+            const int i = e / n, j = e - i * n;
+            A[i * ld + j] = i == j ? 1.0 : 0.0;
+        }
+        __syncthreads();
+        full_rank = ldl_inverse_pair(B2, V, A, n, ld);   // V = L D L' (C00), A = L^-1
+        if (full_rank) {
+            for (int e = tid; e < n * n; e += nt) {
+                const int i = e / n, j = e - i * n;
+                // G = L D^1/2, whitening = G^-T: (D^-1/2 L^-1)' is upper triangular
+                B2[i * ld + j] = j >= i ? A[j * ld + i] / sqrt(V[j * ld + j]) : 0.0;
+            }
+            __syncthreads();
+        } else {
+            __syncthreads();
+            build_cov();   // the attempt overwrote C00
+        }
+    } else {
+        for (int e = tid; e < n * n; e += nt) {
+            const int i = e / n, j = e - i * n;
+            B2[i * ld + j] = A[i * ld + j] - (i == j ? epsilon : 0.0);
+            V[i * ld + j] = A[i * ld + j];
+        }
+        __syncthreads();
+        full_rank = cholesky_lower_pair(B2, V, n, ld, &sh);   // probe on C00 - eps I, factor C00 = G G'
+        if (full_rank) {
+            lower_inverse(V, A, n, ld);         // A = G^-1 (lower)
+            for (int e = tid; e < n * n; e += nt) {
+                const int i = e / n, j = e - i * n;
+                B2[i * ld + j] = j >= i ? A[j * ld + i] : 0.0;  // L = G^-T (upper)
+            }
+            __syncthreads();
+        } else {
+            __syncthreads();
+            build_cov();
+        }
+    }
+    int rank;
+    if (full_rank) {
         rank = n;
         if (tid == 0) *out_rank = n;
     } else {
@@ -655,8 +1064,26 @@ __global__ __launch_bounds__(kEigThreads) void tica_solve_kernel(
         A[i * ld + j] = 0.5 * (V[i * ld + j] + V[j * ld + i]);
     }
     __syncthreads();
-    jacobi_eigh(A, V, rank, ld, &sh, 40);
-    for (int i = tid; i < rank; i += nt) wk.ev[i] = A[i * ld + i];
+    // eigenpairs of the whitened C0t: tridiagonal solver (fallback: Jacobi on the saved copy)
+    const double* Vec = V;
+    bool fast = false;
+    if (kFused && rank <= kTriMax) {
+        for (int e = tid; e < rank * rank; e += nt) wk.A[e] = A[(e / rank) * ld + (e % rank)];
+        __syncthreads();
+        fast = tridiag_eigh(A, V, B1, rank, ld, &ts, 1e-11);
+        if (fast) {
+            for (int i = tid; i < rank; i += nt) wk.ev[i] = ts.lam[i];
+            Vec = A;
+        } else {
+            __syncthreads();
+            for (int e = tid; e < rank * rank; e += nt) A[(e / rank) * ld + (e % rank)] = wk.A[e];
+        }
+        __syncthreads();
+    }
+    if (!fast) {
+        jacobi_eigh(A, V, rank, ld, &sh, 40);
+        for (int i = tid; i < rank; i += nt) wk.ev[i] = A[i * ld + i];
+    }
     __syncthreads();
     sort_desc_abs(wk.ev, rank, wk.order);
     // ---- R = L Rt (sorted), canonical signs, kinetic map ----
@@ -664,7 +1091,7 @@ __global__ __launch_bounds__(kEigThreads) void tica_solve_kernel(
         const int i = e / rank, j = e - i * rank;
         const int src = wk.order[j];
         double a = 0.0;
-        for (int k = 0; k < rank; ++k) a = fma(B2[i * ld + k], V[k * ld + src], a);
+        for (int k = 0; k < rank; ++k) a = fma(B2[i * ld + k], Vec[k * ld + src], a);
         B1[i * ld + j] = a;
     }
     __syncthreads();
@@ -699,6 +1126,24 @@ __global__ __launch_bounds__(kEigThreads) void eigh_kernel(const double* __restr
         A[i * ld + j] = 0.5 * (Ain[e] + Ain[j * n + i]);
     }
     __syncthreads();
+    if constexpr (use_lds) {
+        if (n <= kTriMax) {   // three LDS matrices were requested for this size (jacobi_lds_bytes)
+            __shared__ TriShared ts;
+            double* X = V + (size_t)n * ld;
+            for (int e = tid; e < n * n; e += nt) gA[e] = A[(e / n) * ld + (e % n)];
+            __syncthreads();
+            if (tridiag_eigh(A, V, X, n, ld, &ts, 1e-12)) {
+                for (int j = tid; j < n; j += nt) out_w[j] = ts.lam[j];
+                if (out_v)
+                    for (int e = tid; e < n * n; e += nt) out_v[e] = A[(e / n) * ld + (e % n)];
+                if (tid == 0 && out_sweeps) *out_sweeps = 0;
+                return;
+            }
+            __syncthreads();
+            for (int e = tid; e < n * n; e += nt) A[(e / n) * ld + (e % n)] = gA[e];
+            __syncthreads();
+        }
+    }
     const int sweeps = jacobi_eigh(A, V, n, ld, &sh, 40);
     // ascending order by value
     for (int i = tid; i < n; i += nt) {
@@ -720,7 +1165,7 @@ __global__ __launch_bounds__(kEigThreads) void eigh_kernel(const double* __restr
     if (tid == 0 && out_sweeps) *out_sweeps = sweeps;
 }
 
-size_t jacobi_lds_bytes(int n, int ld) { return (size_t)2 * n * ld * sizeof(double); }
+size_t jacobi_lds_bytes(int n, int ld) { return (size_t)(n <= kTriMax ? 3 : 2) * n * ld * sizeof(double); }
 
 }  // namespace
 
