@@ -226,6 +226,22 @@ msm_status msm_lagged_moments(msm_ctx* ctx, const void* d_x, msm_dtype dtype, in
                               const int64_t* h_seg_start, const int64_t* h_seg_stop, int n_seg, int lag,
                               const double* d_shift, int assume_finite, double* d_moments);
 
+/* The same pass with ONE-SIDED second moments: M00 = sum over X0 only (M0t, sx, sy, T as above).
+ * What the reference's in-repo TICA eigenvalue estimator needs (separate means and covariance of
+ * y_t: _estimate_top_eigenvalues, S/features/deeptica/core/trainer_api.py:641-646). */
+msm_status msm_lagged_moments_onesided(msm_ctx* ctx, const void* d_x, msm_dtype dtype, int64_t n, int F,
+                                       int64_t ld, const int64_t* h_seg_start, const int64_t* h_seg_stop,
+                                       int n_seg, int lag, const double* d_shift, int assume_finite,
+                                       double* d_moments);
+
+/* _estimate_top_eigenvalues (S/features/deeptica/core/trainer_api.py:632-656) from one-sided moments:
+ *   C0 = (M00 - sx sx'/T)/max(1, T-1), Ct = (M0t - sx sy'/T)/max(1, T-1);
+ *   eigh(sym C0) with eigenvalues clipped at `clip` (the reference's NUMERIC_MIN_POSITIVE = 1e-12);
+ *   S = C0^-1/2;  d_eigvals [F] = eigvalsh(sym(S Ct S')) in DESCENDING order (the caller takes the top n_out).
+ * One launch, no host round trip; F <= 256. */
+msm_status msm_onesided_tica_eigenvalues(msm_ctx* ctx, const double* d_moments, int F, double clip,
+                                         double* d_eigvals);
+
 /* The raw column sums msm_column_moments_partial would give ([cnt F][S1 F][S2 F] about d_shift, over every
  * frame of the segments) derived from the lagged moments of the SAME shift and segments plus the first
  * and last `lag` frames of each segment: 2 S1 = sx + sy + edges, 2 S2 = diag(M00) + edges^2.  Saves the

@@ -45,6 +45,7 @@ struct FrameTab {
     int64_t prefix[MSM_SEG_INLINE + 1];
     int64_t total;  // padded frames in those segments
     int64_t pairs;  // T
+    double wy_w;    // weight of the Yt frames in M00: 1 (reversible estimator) or 0 (one-sided: M00 = sum over X0)
 };
 constexpr int kGroup = 4 * kUnroll;
 
@@ -153,7 +154,7 @@ __device__ __forceinline__ void cov_wave_body(const T* __restrict__ x, int F, in
         for (; q0 < q_hi; q0 += 4) {
             // consume the prefetched group into fp64 operands
             double za[NT], zb[NT], zy[NT];
-            const double w = wx + wy;
+            const double w = fma(ft.wy_w, wy, wx);
 #pragma unroll
             for (int a = 0; a < NT; ++a) {
                 const double vx = to_f64(rx[a]);
@@ -387,7 +388,7 @@ __global__ __launch_bounds__(256, 2) void cov_block_kernel(const T* __restrict__
         load_group(t, s_start, s_stop, ra, rb, wx, wy);
         for (; q0 < q_hi; q0 += 4) {
             double za[4], zv[4];
-            const double wb = is_00 ? wx + wy : wx;  // B-side weight: [X0]+[Yt] for M00, [X0] for M0t
+            const double wb = is_00 ? fma(ft.wy_w, wy, wx) : wx;  // B-side weight: [X0]+[Yt] for M00, [X0] for M0t
 #pragma unroll
             for (int a = 0; a < 4; ++a) {
                 const double va = to_f64(ra[a]), vb = to_f64(rb[a]);
@@ -520,11 +521,12 @@ msm_status launch_cov_blocked(msm_ctx* ctx, const T* x, int F, int64_t ld, const
 }
 
 msm_status build_frametab(msm_ctx* ctx, int64_t n, const int64_t* h_start, const int64_t* h_stop, int n_seg, int lag,
-                          FrameTab* out) {
+                          bool one_sided, FrameTab* out) {
     MSM_REQUIRE(ctx, lag >= 0, "lag must be >= 0 (got %d)", lag);   // 0: instantaneous covariance (PCA)
     FrameTab ft;
     memset(&ft, 0, sizeof(ft));
     ft.lag = lag;
+    ft.wy_w = one_sided ? 0.0 : 1.0;
     const int64_t one_a = 0, one_b = n;
     if (n_seg == 0) { h_start = &one_a; h_stop = &one_b; n_seg = 1; }
     MSM_REQUIRE(ctx, h_start && h_stop, "segment arrays are NULL");
@@ -636,15 +638,15 @@ __global__ __launch_bounds__(256) void moments_from_lagged_kernel(const T* __res
 
 extern "C" {
 
-msm_status msm_lagged_moments(msm_ctx* ctx, const void* d_x, msm_dtype dtype, int64_t n, int F, int64_t ld,
-                              const int64_t* h_seg_start, const int64_t* h_seg_stop, int n_seg, int lag,
-                              const double* d_shift, int assume_finite, double* d_moments) {
+static msm_status lagged_moments_impl(msm_ctx* ctx, const void* d_x, msm_dtype dtype, int64_t n, int F, int64_t ld,
+                                      const int64_t* h_seg_start, const int64_t* h_seg_stop, int n_seg, int lag,
+                                      const double* d_shift, int assume_finite, bool one_sided, double* d_moments) {
     if (!ctx) return MSM_ERR_INVALID;
     MSM_REQUIRE(ctx, n >= 0 && F >= 1 && ld >= F, "msm_lagged_moments: need n >= 0, F >= 1, ld >= F");
     MSM_REQUIRE(ctx, dtype == MSM_F32 || dtype == MSM_F64, "msm_lagged_moments: bad dtype");
     MSM_REQUIRE(ctx, d_shift && d_moments && (d_x || n == 0), "msm_lagged_moments: NULL pointer");
     FrameTab ft;
-    msm_status rs = build_frametab(ctx, n, h_seg_start, h_seg_stop, n_seg, lag, &ft);
+    msm_status rs = build_frametab(ctx, n, h_seg_start, h_seg_stop, n_seg, lag, one_sided, &ft);
     if (rs != MSM_OK) return rs;
     if (ft.total == 0) {
         MSM_HIP(ctx, hipMemsetAsync(d_moments, 0, ((size_t)2 * F * F + 2 * F + 1) * sizeof(double), ctx->stream));
@@ -653,6 +655,20 @@ msm_status msm_lagged_moments(msm_ctx* ctx, const void* d_x, msm_dtype dtype, in
     if (dtype == MSM_F32)
         return dispatch_cov<float>(ctx, (const float*)d_x, F, ld, ft, d_shift, assume_finite != 0, d_moments);
     return dispatch_cov<double>(ctx, (const double*)d_x, F, ld, ft, d_shift, assume_finite != 0, d_moments);
+}
+
+msm_status msm_lagged_moments(msm_ctx* ctx, const void* d_x, msm_dtype dtype, int64_t n, int F, int64_t ld,
+                              const int64_t* h_seg_start, const int64_t* h_seg_stop, int n_seg, int lag,
+                              const double* d_shift, int assume_finite, double* d_moments) {
+    return lagged_moments_impl(ctx, d_x, dtype, n, F, ld, h_seg_start, h_seg_stop, n_seg, lag, d_shift, assume_finite,
+                               false, d_moments);
+}
+
+msm_status msm_lagged_moments_onesided(msm_ctx* ctx, const void* d_x, msm_dtype dtype, int64_t n, int F, int64_t ld,
+                                       const int64_t* h_seg_start, const int64_t* h_seg_stop, int n_seg, int lag,
+                                       const double* d_shift, int assume_finite, double* d_moments) {
+    return lagged_moments_impl(ctx, d_x, dtype, n, F, ld, h_seg_start, h_seg_stop, n_seg, lag, d_shift, assume_finite,
+                               true, d_moments);
 }
 
 msm_status msm_moments_from_lagged(msm_ctx* ctx, const void* d_x, msm_dtype dtype, int64_t n, int F, int64_t ld,

@@ -1165,6 +1165,100 @@ __global__ __launch_bounds__(kEigThreads) void eigh_kernel(const double* __restr
     if (tid == 0 && out_sweeps) *out_sweeps = sweeps;
 }
 
+// Eigenvalue estimator of the reference's DeepTICA trainer (_estimate_top_eigenvalues,
+// S/features/deeptica/core/trainer_api.py:632-656) from ONE-SIDED raw moments (msm_lagged_moments_onesided):
+//   C0 = (M00 - sx sx'/T) / max(1, T-1),  Ct = (M0t - sx sy'/T) / max(1, T-1)      (separate means of y_t, y_tau)
+//   eigh(sym C0), eigenvalues clipped at `clip`; S = V diag(w^-1/2) V';  eigvalsh(sym(S Ct S')), descending.
+// Four n x n matrices P0..P3 (LDS when they fit, else global), eigensolves by tridiag_eigh with the Jacobi fallback.
+template <bool use_lds>
+__global__ __launch_bounds__(kEigThreads) void onesided_eig_kernel(const double* __restrict__ mom, int n, int ld,
+                                                                  double clip, double* gP, double* gbak, double* gw,
+                                                                  int* order, double* __restrict__ out_eig) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    __shared__ JacobiShared sh;
+    __shared__ TriShared ts;
+    const int tid = threadIdx.x, nt = blockDim.x;
+    const size_t mat = (size_t)n * ld;
+    double* P0 = use_lds ? reinterpret_cast<double*>(smem_raw) : gP;
+    double *P1 = P0 + mat, *P2 = P0 + 2 * mat, *P3 = P0 + 3 * mat;
+    const double* M00 = mom;
+    const double* M0t = mom + (size_t)n * n;
+    const double* sx = M0t + (size_t)n * n;
+    const double* sy = sx + n;
+    const double T = sy[n];
+    if (!(T > 0.0)) {
+        for (int i = tid; i < n; i += nt) out_eig[i] = 0.0;
+        return;
+    }
+    const double den = T - 1.0 > 1.0 ? T - 1.0 : 1.0;
+    for (int e = tid; e < n * n; e += nt) {
+        const int i = e / n, j = e - i * n;
+        const double c0 = 0.5 * (M00[e] + M00[j * n + i]) - sx[i] * sx[j] / T;
+        P0[i * ld + j] = c0 / den;
+        P1[i * ld + j] = (M0t[e] - sx[i] * sy[j] / T) / den;
+    }
+    __syncthreads();
+    // eigenpairs of the symmetric matrix in P0 (work P2, P3): eigenvalues to gw, eigenvectors to *vec
+    auto eigh = [&](const double*& vec) {
+        bool fast = false;
+        if (use_lds && n <= kTriMax) {
+            for (int e = tid; e < n * n; e += nt) gbak[e] = P0[(e / n) * ld + (e % n)];
+            __syncthreads();
+            fast = tridiag_eigh(P0, P2, P3, n, ld, &ts, 1e-12);
+            if (fast) {
+                for (int i = tid; i < n; i += nt) gw[i] = ts.lam[i];
+                vec = P0;
+            } else {
+                __syncthreads();
+                for (int e = tid; e < n * n; e += nt) P0[(e / n) * ld + (e % n)] = gbak[e];
+            }
+            __syncthreads();
+        }
+        if (!fast) {
+            jacobi_eigh(P0, P2, n, ld, &sh, 40);
+            for (int i = tid; i < n; i += nt) gw[i] = P0[i * ld + i];
+            vec = P2;
+            __syncthreads();
+        }
+    };
+    const double* vec = nullptr;
+    eigh(vec);
+    // P3 = V diag(w^-1/4): S = P3 P3'
+    for (int e = tid; e < n * n; e += nt) {
+        const int i = e / n, j = e - i * n;
+        const double wj = gw[j] > clip ? gw[j] : clip;
+        P3[i * ld + j] = vec[i * ld + j] / sqrt(sqrt(wj));
+    }
+    __syncthreads();
+    for (int e = tid; e < n * n; e += nt) {   // S -> P0
+        const int i = e / n, j = e - i * n;
+        double a = 0.0;
+        for (int k = 0; k < n; ++k) a = fma(P3[i * ld + k], P3[j * ld + k], a);
+        P0[i * ld + j] = a;
+    }
+    __syncthreads();
+    small_mm(P2, P0, false, P1, n, n, n, ld);   // S Ct
+    small_mm(P3, P2, false, P0, n, n, n, ld);   // (S Ct) S'   (S is symmetric)
+    for (int e = tid; e < n * n; e += nt) {
+        const int i = e / n, j = e - i * n;
+        P0[i * ld + j] = 0.5 * (P3[i * ld + j] + P3[j * ld + i]);
+    }
+    __syncthreads();
+    eigh(vec);
+    // descending order
+    for (int i = tid; i < n; i += nt) {
+        const double a = gw[i];
+        int rank = 0;
+        for (int j = 0; j < n; ++j) {
+            const double b = gw[j];
+            rank += (b > a) || (b == a && j < i);
+        }
+        order[rank] = i;
+    }
+    __syncthreads();
+    for (int j = tid; j < n; j += nt) out_eig[j] = gw[order[j]];
+}
+
 size_t jacobi_lds_bytes(int n, int ld) { return (size_t)(n <= kTriMax ? 3 : 2) * n * ld * sizeof(double); }
 
 }  // namespace
@@ -1196,6 +1290,31 @@ msm_status msm_tica_solve(msm_ctx* ctx, const double* d_moments, const double* d
         MSM_HIP(ctx, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(kern, dim3(1), dim3(kEigThreads), lds, ctx->stream, d_moments, d_scale, F, ld, epsilon,
                        kinetic_map, wk, d_eigvals, d_coeffs, d_mean, d_rank);
+    MSM_CHECK_LAUNCH(ctx);
+    return MSM_OK;
+}
+
+msm_status msm_onesided_tica_eigenvalues(msm_ctx* ctx, const double* d_moments, int F, double clip, double* d_eigvals) {
+    if (!ctx) return MSM_ERR_INVALID;
+    MSM_REQUIRE(ctx, F >= 1 && F <= 2 * kMaxPairs, "msm_onesided_tica_eigenvalues: need 1 <= F <= %d (got %d)",
+                2 * kMaxPairs, F);
+    MSM_REQUIRE(ctx, d_moments && d_eigvals && clip > 0.0, "msm_onesided_tica_eigenvalues: bad arguments");
+    const int ld = F | 1;
+    const size_t mat = (size_t)F * ld;
+    const size_t lds = 4 * mat * sizeof(double);
+    const bool use_lds = lds <= 140 * 1024;
+    msm_status rs = msm_reserve_scratch(ctx, ((use_lds ? 0 : 4 * mat) + (size_t)F * F + F) * sizeof(double) +
+                                                 (size_t)F * sizeof(int) + 64);
+    if (rs != MSM_OK) return rs;
+    double* gP = (double*)ctx->scratch;
+    double* gbak = gP + (use_lds ? 0 : 4 * mat);
+    double* gw = gbak + (size_t)F * F;
+    int* order = (int*)(gw + F);
+    auto kern = use_lds ? onesided_eig_kernel<true> : onesided_eig_kernel<false>;
+    if (use_lds && lds > 48 * 1024)
+        MSM_HIP(ctx, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(kern, dim3(1), dim3(kEigThreads), use_lds ? lds : 0, ctx->stream, d_moments, F, ld, clip, gP, gbak,
+                       gw, order, d_eigvals);
     MSM_CHECK_LAUNCH(ctx);
     return MSM_OK;
 }

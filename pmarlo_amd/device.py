@@ -366,16 +366,24 @@ class Engine:
         return mean, scale, inv
 
     def lagged_moments(self, x: DeviceArray, lag: int, shift: DeviceArray, *, starts=None, stops=None,
-                       assume_finite: bool = False, out: DeviceArray | None = None) -> DeviceArray:
-        """Raw reversible lagged moments [M00 | M0t | sx | sy | T] (2F^2+2F+1 f64)."""
+                       assume_finite: bool = False, out: DeviceArray | None = None,
+                       one_sided: bool = False) -> DeviceArray:
+        """Raw lagged moments [M00 | M0t | sx | sy | T] (2F^2+2F+1 f64): the reversible estimator's
+        (M00 over X0 and Yt) or, with one_sided, M00 over X0 only."""
         n, F = x.shape
         if starts is None:
             starts, stops = segments_to_bounds(None, n)
         starts, stops = self._seg_ptrs(starts, stops)
         out = out if out is not None else self.empty((2 * F * F + 2 * F + 1,), np.float64)
-        check(lib.msm_lagged_moments(self.handle, x.ptr, _dtype_code(x.dtype), n, F, F, starts.ctypes.data,
-                                     stops.ctypes.data, len(starts), int(lag), shift.ptr, int(bool(assume_finite)),
-                                     out.ptr), self.handle)
+        fn = lib.msm_lagged_moments_onesided if one_sided else lib.msm_lagged_moments
+        check(fn(self.handle, x.ptr, _dtype_code(x.dtype), n, F, F, starts.ctypes.data, stops.ctypes.data, len(starts),
+                 int(lag), shift.ptr, int(bool(assume_finite)), out.ptr), self.handle)
+        return out
+
+    def onesided_tica_eigenvalues(self, moments: DeviceArray, F: int, clip: float = 1e-12) -> DeviceArray:
+        """Descending eigenvalues of the reference's in-repo estimator from one-sided moments."""
+        out = self.empty((F,), np.float64)
+        check(lib.msm_onesided_tica_eigenvalues(self.handle, moments.ptr, int(F), float(clip), out.ptr), self.handle)
         return out
 
     def moments_from_lagged(self, x: DeviceArray, lag: int, shift: DeviceArray, moments: DeviceArray, *, starts=None,

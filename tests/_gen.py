@@ -25,6 +25,20 @@ def correlated_series(n_frames: int, n_features: int, seed: int) -> np.ndarray:
     return out
 
 
+def correlated_series_loop(n_frames: int, n_features: int, seed: int) -> np.ndarray:
+    """The same recipe in the reference's LOOP form (tests/perf/test_tica_perf.py:65-81): these are the values
+    the reference's own benchmark feeds its estimators (the fixtures store their hash)."""
+    rng = np.random.default_rng(seed)
+    latent = np.zeros((n_frames, 3))
+    for t in range(1, n_frames):
+        latent[t, 0] = 0.985 * latent[t - 1, 0] + rng.normal(scale=0.05)
+        latent[t, 1] = 0.950 * latent[t - 1, 1] + rng.normal(scale=0.08)
+        latent[t, 2] = rng.normal(scale=0.5)
+    mixing = rng.normal(scale=0.7, size=(3, n_features))
+    noise = rng.normal(scale=0.05, size=(n_frames, n_features))
+    return (latent @ mixing + noise).astype(np.float32)
+
+
 def gaussian_clusters(n_clusters: int, per: int, d: int, seed: int):
     """tests/perf/test_discretize_assignment_perf.py:30-48 recipe."""
     rng = np.random.default_rng(seed)

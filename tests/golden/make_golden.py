@@ -147,6 +147,24 @@ def golden_preprocess_tica():
     Yp = _preprocess(Y, scale=True)
     ev = _estimate_top_eigenvalues(Yp, idx_t, idx_tau, SimpleNamespace(n_out=8))
     out.update(tica_X=Y, tica_lag=np.int64(lag), tica_top_eigs=np.asarray(ev))
+    # the reference's own benchmark input of this estimator (tests/perf/test_tica_perf.py:216-235): raw AR(1)
+    # series, N = 20 000, F = 8, seed 21, lag 10.  Only its hash is stored: tests regenerate it (tests/_gen.py).
+    P = correlated_series(20_000, 8, 21)
+    ip = np.arange(0, P.shape[0] - lag)
+    evp = _estimate_top_eigenvalues(P, ip, ip + lag, SimpleNamespace(n_out=8))
+    # arbitrary (non-run) pairs on the same input: every third frame against frame + 7 and + 13 alternately
+    it = np.arange(0, P.shape[0] - 20, 3)
+    itau = it + np.where(np.arange(it.size) % 2 == 0, 7, 13)
+    evq = _estimate_top_eigenvalues(P, it, itau, SimpleNamespace(n_out=8))
+    # float32 outputs make the reference work in float32 throughout (centring, both products, both LAPACK calls):
+    # its own answer then carries ~1e-6 of single-precision error.  The same series as float64 gives the values an
+    # fp64 implementation can be held to at 1e-9.
+    P64 = P.astype(np.float64)
+    evp64 = _estimate_top_eigenvalues(P64, ip, ip + lag, SimpleNamespace(n_out=8))
+    evq64 = _estimate_top_eigenvalues(P64, it, itau, SimpleNamespace(n_out=8))
+    out.update(perf_input_sha=np.frombuffer(bytes.fromhex(sha(P)), np.uint8), perf_lag=np.int64(lag),
+               perf_top_eigs=np.asarray(evp), perf_pairs_eigs=np.asarray(evq),
+               perf_top_eigs_f64=np.asarray(evp64), perf_pairs_eigs_f64=np.asarray(evq64))
     np.savez_compressed(OUT / "tica.npz", **out)
 
 
