@@ -1,18 +1,24 @@
 #!/usr/bin/env python3
-"""Benchmark of the hot path: featurised shard -> TICA -> k-means -> transition matrix.
+"""Benchmark of the hot path: (featurize ->) TICA -> k-means -> transition matrix on one shard per GPU.
 
 Contract (driver): ``python bench.py --gpus N --steps K --warmup W``; for N > 1 launched by
-torch.distributed.run with one rank per GPU (RCCL).  Rank 0 prints ONE JSON line.
+torch.distributed.run with one rank per GPU (only RANK / LOCAL_RANK / WORLD_SIZE / MASTER_PORT are read: the
+exchange is RCCL through the C ABI, pmarlo_amd/dist.py NativeComm).  Rank 0 prints ONE JSON line.
 
-Workload (BASELINE.json metric "... 1Mx64 synth"): per GPU one synthetic shard of
+Headline workload (BASELINE.json metric "... 1Mx64 synth", --config c3): per GPU one synthetic shard of
 1,000,000 frames x 64 float32 features (AR(1)-latent generator of the reference's
-tests/perf/test_tica_perf.py:65-81, vectorised; seed 1000 + rank), already resident in
-HBM when the timed region starts.  One step = one pass of the whole path over the shard:
-fp64-MFMA lagged covariance (the standardisation sums come out of it) -> on-device TICA solve
-(dim 10) -> projection (with max |Y| for the fixed-point scale) -> k-means (k = 500, seeded init + 10 full-batch Lloyd iterations, fp64-MFMA
-assignment) -> final assignment -> lag-10 transition counts -> row-normalised T.
-Weak scaling: every rank holds its own shard; only the small moment / count / centre
-buffers are all-reduced (pmarlo_amd/dist.py).
+tests/perf/test_tica_perf.py:65-81, vectorised; seed 1000 + rank), resident in HBM when the timed region starts.
+One step = one pass of the whole path over the shard: fp64-MFMA lagged covariance (the standardisation sums
+come out of it) -> on-device TICA solve (dim 10) -> projection (with max |Y|) -> bf16 frame images -> k-means
+(k = 500, seeded start + 10 full-batch Lloyd iterations: certified bf16 matrix-core filter + pinned fp64
+refinement) -> final assignment -> lag-10 transition counts -> row-normalised T.
+Weak scaling: every rank holds its own shard; only the small moment / member-sum / count buffers are all-reduced.
+
+Other workloads (--config): c4 = BASELINE config 4 (chignolin: xyz -> 45 C-alpha distances on the device every
+step -> k = 200 in the feature space -> lag scan 1..50 in one pass and one collective); c5 / c5t = BASELINE
+config 5 per GPU (1.25 M x 256 float32, k = 2000; clustering in the raw 256-d space / after TICA -> 10).
+Extra legs at N = 1 (reported beside the headline, never as it): the featurizer alone and in front of the c3
+chain, the operator API from host arrays, k-means quality against the CPU baseline, per-stage times.
 """
 
 from __future__ import annotations
@@ -29,16 +35,30 @@ import numpy as np
 ROOT = Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT))
 
-N_FRAMES, N_FEATURES, TICA_DIM, K_STATES, LAG, KMEANS_ITERS = 1_000_000, 64, 10, 500, 10, 10
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s
 FP64_MFMA_PEAK_TF = 78.6       # MI355X fp64 matrix (= vector) peak
-# HBM-side bytes per launch of the dominant kernel at the default workload, from the PMC passes in
-# profiles/r01_pmc_hbm.md (2 x FETCH_SIZE + WRITE_SIZE, the gfx950 correction of the guide):
-# reads of Y (80 MB) + the atomics flush of the member sums
-KMEANS_ACCUM_TRAFFIC_BYTES = (2 * 39293 + 10667) * 1024
+BF16_MFMA_PEAK_TF = 2500.0     # dense bf16 matrix peak
+
+CONFIGS = {
+    #        frames/GPU  F    tica  k     lag  iters
+    "c3": dict(n=1_000_000, F=64, d=10, k=500, lag=10, iters=10),
+    "c4": dict(n=1_000_000, F=45, d=0, k=200, lag=10, iters=10, lags=tuple(range(1, 51)), atoms=138),
+    "c5": dict(n=1_250_000, F=256, d=0, k=2000, lag=10, iters=10),
+    "c5t": dict(n=1_250_000, F=256, d=10, k=2000, lag=10, iters=10),
+}
 
 
-def cpu_baseline(X: np.ndarray) -> dict:
+def chignolin_frames(n: int, seed: int):
+    """BASELINE config 4 input: the 18 NMR models of data/chignolin.pdb tiled cyclically (nm),
+    plus N(0, 0.02 nm) noise; coordinates and C-alpha pairs come from the committed fixture."""
+    g = np.load(ROOT / "tests" / "golden" / "featurizer.npz")
+    base = g["chig_xyz"][:18].astype(np.float32)
+    rng = np.random.default_rng(seed)
+    xyz = base[np.arange(n) % 18] + rng.normal(0.0, 0.02, size=(n, base.shape[1], 3)).astype(np.float32)
+    return xyz, g["chig_pairs"].astype(np.int32)
+
+
+def cpu_baseline(X: np.ndarray, c: dict) -> dict:
     """The oracle's numpy / scikit-learn restatement of the same path (what the reference runs at
     this size: _preprocess -> TICA -> MiniBatchKMeans branch (n*d >= 5e6) -> predict ->
     _weighted_counts -> _normalise_counts), timed once on this host."""
@@ -46,13 +66,15 @@ def cpu_baseline(X: np.ndarray) -> dict:
 
     t0 = time.perf_counter()
     Xp = npport.preprocess(X, scale=True)
-    model = npport.tica_fit([Xp], LAG, dim=TICA_DIM)
+    model = npport.tica_fit([Xp], c["lag"], dim=c["d"])
     Y = npport.tica_transform(model, Xp)
-    fit = npport.kmeans_discretizer_fit(Y, K_STATES, random_state=0)
-    labels = npport.kmeans_predict((Y - fit["mean"]) / fit["std_safe"], fit["centers"])
-    counts, _ = npport.weighted_counts(labels, K_STATES, LAG)
+    fit = npport.kmeans_discretizer_fit(Y, c["k"], random_state=0)
+    Yz = (Y - fit["mean"]) / fit["std_safe"]
+    labels = npport.kmeans_predict(Yz, fit["centers"])
+    counts, _ = npport.weighted_counts(labels, c["k"], c["lag"])
     npport.normalise_counts(counts)
     dt = time.perf_counter() - t0
+    inertia = float(((Yz - fit["centers"][labels]) ** 2).sum())
     try:
         from threadpoolctl import threadpool_info
 
@@ -62,7 +84,90 @@ def cpu_baseline(X: np.ndarray) -> dict:
     return {"value": X.shape[0] / dt, "unit": "frames/s", "cores": int(threads), "kind": "port",
             "sample": f"the full {X.shape[0]}x{X.shape[1]} shard once, {dt:.1f} s "
                       "(numpy TICA + sklearn MiniBatchKMeans + predict + numpy counts)",
-            "tica_eigenvalues": model["eigenvalues"][:TICA_DIM].tolist()}
+            "tica_eigenvalues": model["eigenvalues"][:c["d"]].tolist(), "inertia_whitened": inertia,
+            "_Yz": Yz}
+
+
+def featurize_legs(eng, c3: dict) -> dict:
+    """The featurizer alone (HBM GB/s against the algorithmic 12 A + 4 F bytes per frame) at the C4 shape and at a
+    64-feature synthetic shape, and the c3 chain with the featurizer in front (xyz resident, features rebuilt by
+    every step)."""
+    from pmarlo_amd.dist import ShardConfig, ShardedMSM
+
+    out = {}
+    n = 1_000_000
+    for name, A, F in (("c4_chignolin_45_ca_pairs", 138, 45), ("synthetic_128_atoms_64_pairs", 128, 64)):
+        rng = np.random.default_rng(7)
+        if A == 138:
+            xyz, pairs = chignolin_frames(n, 1234)
+        else:
+            xyz = rng.normal(0.0, 1.0, size=(n, A, 3)).astype(np.float32)
+            pairs = np.stack([rng.integers(0, A, F), rng.integers(0, A, F)], 1).astype(np.int32)
+            pairs[:, 1] = np.where(pairs[:, 1] == pairs[:, 0], (pairs[:, 0] + 1) % A, pairs[:, 1])
+        xd = eng.to_device(xyz)
+        pd = eng.to_device(pairs)
+        feat = eng.empty((n, F), np.float32)
+        for _ in range(3):
+            eng.featurize_distances_into(xd, pd, feat)
+        eng.sync()
+        evs = []
+        for _ in range(10):
+            a, b = eng.event(), eng.event()
+            a.record()
+            eng.featurize_distances_into(xd, pd, feat)
+            b.record()
+            evs.append((a, b))
+        eng.sync()
+        ms = float(np.median([a.elapsed_ms(b) for a, b in evs]))
+        bytes_alg = n * (12 * A + 4 * F)
+        out[name] = {"frames": n, "atoms": A, "features": F, "ms": ms, "frames_per_s": n / (ms * 1e-3),
+                     "algorithmic_bytes": bytes_alg, "GBps": bytes_alg / (ms * 1e-3) / 1e9,
+                     "frac_of_hbm_peak": bytes_alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
+        if A == 128:
+            # the headline chain behind the featurizer: xyz -> 64 distances -> TICA -> k-means -> T
+            cfg = ShardConfig(n_frames=n, n_features=F, tica_dim=c3["d"], k=c3["k"], lag=c3["lag"],
+                              kmeans_iters=c3["iters"], seed=0, n_total=n, n_atoms=A, pairs=pairs)
+            msm = ShardedMSM(eng, cfg, xd)
+            for _ in range(2):
+                msm.step()
+            eng.sync()
+            t0 = time.perf_counter()
+            for _ in range(5):
+                msm.step()
+            eng.sync()
+            dt = (time.perf_counter() - t0) / 5
+            out["chain_with_featurizer"] = {"workload": f"xyz {n} x {A} atoms -> {F} pair distances -> the c3 chain",
+                                            "ms_per_step": dt * 1e3, "frames_per_s": n / dt}
+            del msm
+        del xd, feat
+    return out
+
+
+def operator_api_leg(X: np.ndarray, c: dict) -> dict:
+    """The pmarlo-shaped operators from HOST arrays (upload and download inside the clock)."""
+    from pmarlo_amd.analysis.discretize import discretize_dataset
+    from pmarlo_amd.markov_state_model.clustering import cluster_microstates
+    from pmarlo_amd.markov_state_model.reduction import tica_reduce
+
+    out = {}
+    t0 = time.perf_counter()
+    Y = tica_reduce(X, lag=c["lag"], n_components=c["d"])
+    t1 = time.perf_counter()
+    res = cluster_microstates(Y, method="kmeans", n_states=c["k"], random_state=0, max_iter=c["iters"], tolerance=0.0)
+    t2 = time.perf_counter()
+    ds = {"splits": {"train": {"X": Y, "segments": [{"start": 0, "stop": Y.shape[0]}]}}}
+    dres = discretize_dataset(ds, cluster_mode="kmeans", n_microstates=c["k"], lag_time=c["lag"], random_state=0)
+    t3 = time.perf_counter()
+    n = X.shape[0]
+    out["tica_reduce_ms"] = (t1 - t0) * 1e3
+    out["cluster_microstates_ms"] = (t2 - t1) * 1e3
+    out["discretize_dataset_ms"] = (t3 - t2) * 1e3
+    out["frames_per_s_tica_plus_cluster"] = n / (t2 - t0)
+    out["frames_per_s_all_three"] = n / (t3 - t0)
+    out["n_states_found"] = int(res.n_states)
+    out["counted_pairs"] = int(dres.counted_pairs.get("train", 0)) if hasattr(dres, "counted_pairs") else None
+    out["note"] = "host numpy in, host numpy out: PCIe transfers and host bookkeeping are inside these times"
+    return out
 
 
 def main() -> None:
@@ -70,105 +175,148 @@ def main() -> None:
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--config", choices=sorted(CONFIGS), default="c3")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-single-thread", action="store_true",
-                    help="also time the CPU restatement pinned to one thread on the full shard (about a minute)")
-    ap.add_argument("--frames", type=int, default=N_FRAMES, help="frames per GPU (default: the BASELINE config)")
+    ap.add_argument("--no-extra-legs", action="store_true", help="skip the featurizer / operator-API / quality legs")
+    ap.add_argument("--frames", type=int, default=0, help="frames per GPU (default: the config's)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    # BENCH_FORCE_EXCHANGE=1 (under torch.distributed.run with one rank): keep every collective in the
-    # step, so a one-GPU box exercises the RCCL calls the N > 1 runs make
+    # BENCH_FORCE_EXCHANGE=1 (one rank): keep every collective in the step, so a one-GPU box exercises the
+    # RCCL calls the N > 1 runs make
     multi = world > 1 or os.environ.get("BENCH_FORCE_EXCHANGE") == "1"
     if args.gpus != world and rank == 0:
         print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
 
     from pmarlo_amd.device import Engine
-    from pmarlo_amd.dist import ShardConfig, ShardedMSM, TorchComm, torch_exchange_buffers
+    from pmarlo_amd.dist import (NativeComm, ShardConfig, ShardedMSM, TorchComm, exchange_aliases, exchange_shapes,
+                                 torch_exchange_buffers)
     from tests import _gen
 
-    comm = None
-    shared = None
-    if multi:
+    c = dict(CONFIGS[args.config])
+    n = int(args.frames) if args.frames else c["n"]
+    F, d, k, lag, iters = c["F"], c["d"], c["k"], c["lag"], c["iters"]
+    cfg_kw = dict(n_frames=n, n_features=F, tica_dim=d, k=k, lag=lag, kmeans_iters=iters, seed=0, n_total=n * world,
+                  lags=c.get("lags"))
+
+    # ---- transport: RCCL through the C ABI (default), or torch.distributed (BENCH_COMM=torch; BENCH_BACKEND=gloo
+    # and BENCH_SAME_GPU=1 rehearse several ranks on one GPU)
+    comm_kind = os.environ.get("BENCH_COMM", "rccl") if multi else None
+    comm, shared, dist = None, None, None
+    same_gpu = os.environ.get("BENCH_SAME_GPU") == "1"
+    if same_gpu:
+        local_rank = 0
+    if comm_kind == "torch":
         import torch
         import torch.distributed as dist
 
-        # rehearsal knobs (a one-GPU box cannot host two RCCL ranks): BENCH_BACKEND=gloo and
-        # BENCH_SAME_GPU=1 run every rank on device 0 with gloo moving the (device) buffers
-        backend = os.environ.get("BENCH_BACKEND", "nccl")
-        if os.environ.get("BENCH_SAME_GPU") == "1":
-            local_rank = 0
         torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend)
-        # one explicit stream shared by the engine's kernels and torch's collectives (the default
-        # stream's handle is 0, which the C ABI reads as "create your own stream")
+        dist.init_process_group(os.environ.get("BENCH_BACKEND", "nccl"))
         stream = torch.cuda.Stream(device=local_rank)
         torch.cuda.set_stream(stream)
         eng = Engine(local_rank, stream=stream.cuda_stream)
     else:
         eng = Engine(local_rank)
 
-    n = int(args.frames)
-    cfg = ShardConfig(n_frames=n, n_features=N_FEATURES, tica_dim=TICA_DIM, k=K_STATES, lag=LAG,
-                      kmeans_iters=KMEANS_ITERS, seed=0, n_total=n * world)
-    X = _gen.correlated_series(n, N_FEATURES, seed=1000 + rank)
-    xd = eng.to_device(X)
-    if multi:
+    if c.get("atoms"):
+        xyz, pairs = chignolin_frames(n, 1234 + rank)
+        X = None
+        xd = eng.to_device(xyz)
+        cfg = ShardConfig(**cfg_kw, n_atoms=c["atoms"], pairs=pairs)
+    else:
+        X = _gen.correlated_series(n, F, seed=1000 + rank)
+        xd = eng.to_device(X)
+        cfg = ShardConfig(**cfg_kw)
+
+    if comm_kind == "torch":
         tensors, shared = torch_exchange_buffers(eng, cfg, torch.device("cuda", local_rank))
+        tensors["timing"] = torch.zeros((1,), dtype=torch.float64, device=torch.device("cuda", local_rank))
+        shared["timing"] = eng.wrap(tensors["timing"].data_ptr(), (1,), np.dtype(np.float64))
         comm = TorchComm(tensors)
+    elif comm_kind == "rccl":
+        shared = {nm: eng.zeros(shape, np.dtype(dt)) for nm, (shape, dt) in exchange_shapes(cfg).items()}
+        shared["timing"] = eng.zeros((1,), np.float64)
+        comm = NativeComm.from_env(eng, shared)
     msm = ShardedMSM(eng, cfg, xd, comm=comm, shared=shared, always_exchange=multi)
 
     def barrier():
         eng.sync()
         if multi:
-            torch.cuda.synchronize()
-            dist.barrier()
-            torch.cuda.synchronize()
+            comm.allreduce_max("timing")     # a collective every rank must enter
+            eng.sync()
+            if comm_kind == "torch":
+                torch.cuda.synchronize()
 
     for _ in range(max(0, args.warmup)):
         msm.step()
     barrier()
     msm.time_accum = True
+    msm.time_stages = True
+    n_coll0 = comm.n_collectives if multi else 0
     t0 = time.perf_counter()
     for _ in range(args.steps):
         msm.step()
     barrier()
     elapsed = time.perf_counter() - t0
     msm.time_accum = False
+    msm.time_stages = False
+    n_coll = (comm.n_collectives - n_coll0 - 1) if multi else 0     # minus the barrier's own collective
     if multi:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        shared["timing"].copy_from_host(np.array([elapsed]))
+        comm.allreduce_max("timing")
+        eng.sync()
+        elapsed = float(shared["timing"].to_host()[0])
 
-    # from-host pass: the same step with the shard uploaded from pageable host
-    # memory inside the clock -- reported beside `value`, never as it
-    from_host = None
-    if world == 1 and not multi:
-        eng.sync()
-        t1 = time.perf_counter()
-        xd2 = eng.to_device(X)
-        eng.sync()
-        h2d = time.perf_counter() - t1
-        msm.x = xd2
-        msm.step()
-        eng.sync()
-        tot = time.perf_counter() - t1
-        msm.x = xd
-        del xd2
-        from_host = {"value": n / tot, "unit": "frames/s", "h2d_ms": h2d * 1e3, "step_ms": (tot - h2d) * 1e3,
-                     "h2d_GBps": X.nbytes / h2d / 1e9, "note": "one pageable-memory upload + one step"}
+    # ---- per-stage device times (HIP events on the engine's stream, inside the timed steps)
+    names = [s for s in ("begin", "featurize", "moments", "tica_solve", "project", "kmeans", "counts") if s in msm.stage_events]
+    stages = {}
+    for a, b_ in zip(names[:-1], names[1:]):
+        stages[b_] = float(np.mean([x.elapsed_ms(y) for x, y in zip(msm.stage_events[a], msm.stage_events[b_])]))
 
-    # dominant kernel: k-means assign+accumulate (fp64 MFMA), measured with HIP events on the
-    # engine's stream inside the timed region
+    # dominant kernel: the k-means assign + accumulate pass, measured with HIP events on the engine's stream
     acc_ms = [a.elapsed_ms(b) for a, b in msm.accum_events]
     acc_ms_avg = float(np.mean(acc_ms)) if acc_ms else float("nan")
-    flops_per_launch = 2.0 * K_STATES * TICA_DIM * n            # 2*k*d per frame
+    dc = cfg.cluster_dim
+    flops_per_launch = 2.0 * k * dc * n            # 2 k d per frame
     achieved_tf = flops_per_launch / (acc_ms_avg * 1e-3) / 1e12
+    filtered = msm.km_image is not None
+    roofline = {"bound": "mfma", "achieved": achieved_tf, "peak": FP64_MFMA_PEAK_TF, "unit": "TFLOP/s",
+                "frac": achieved_tf / FP64_MFMA_PEAK_TF, "traffic": None,
+                "launch_ms": acc_ms_avg, "launches_timed": len(acc_ms), "algorithmic_flops_per_launch": flops_per_launch}
+    if filtered:
+        nm = 1 if 6 * dc + 4 <= 32 else 2
+        tiles = ((((k + 15) // 16) + 1) // 2) * 2
+        exec_flops = float(-(-n // 16)) * tiles * nm * 16384.0      # bf16 16x16x32 instructions issued
+        roofline.update(
+            kernel="kmeans_filter_kernel<double,2,4,true,false> (assign + accumulate: bf16x3 matrix-core filter, "
+                   "pinned fp64 refinement)",
+            note="achieved / peak / frac price the ALGORITHMIC fp64 work (2 k d flop per frame) against the fp64 matrix "
+                 "peak, the rate an all-fp64 pass is bounded by; frac above 1 is what the exact bf16 filter buys. "
+                 "`executed` prices the bf16 matrix instructions the kernel really issues against the bf16 peak.",
+            executed={"dtype": "bf16", "flops_per_launch": exec_flops,
+                      "achieved": exec_flops / (acc_ms_avg * 1e-3) / 1e12, "peak": BF16_MFMA_PEAK_TF, "unit": "TFLOP/s",
+                      "frac": exec_flops / (acc_ms_avg * 1e-3) / 1e12 / BF16_MFMA_PEAK_TF})
+    else:
+        roofline.update(kernel="kmeans_mfma_kernel (assign + accumulate, fp64 MFMA)")
+    prof = ROOT / "profiles" / "r02_pmc_hbm.json"
+    if prof.exists() and args.config == "c3" and n == CONFIGS["c3"]["n"]:
+        try:
+            pj = json.loads(prof.read_text())
+            if pj.get("kernel_prefix", "x") in roofline["kernel"]:
+                roofline["traffic"] = pj.get("bytes_per_launch")
+                roofline["traffic_unit"] = "bytes per launch (rocprofv3 PMC, profiles/r02_pmc_hbm.md)"
+        except Exception:
+            pass
 
     if rank == 0:
         total_frames = float(n) * world * args.steps
+        workload = (f"synthetic {n} frames x {F} f32 features per GPU (AR(1) latents), "
+                    + (f"TICA->{d}, " if d else "no TICA, ") + f"k={k} ({iters} Lloyd iterations), lag={lag}, row-normalised T")
+        if c.get("atoms"):
+            workload = (f"chignolin-shaped xyz {n} frames x {c['atoms']} atoms per GPU -> {F} C-alpha distances on the device, "
+                        f"k={k} in the feature space ({iters} Lloyd iterations), lag scan 1..{len(c['lags'])} in one pass")
         out = {
             "metric": "frames/sec featurize->TICA->k-means->T-matrix, 1Mx64 synth; ITS rel-err",
             "value": total_frames / elapsed,
@@ -182,79 +330,134 @@ def main() -> None:
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
-            "config": {"workload": f"synthetic {n} frames x {N_FEATURES} f32 features per GPU (AR(1) latents), "
-                                   f"TICA->{TICA_DIM}, k={K_STATES} ({KMEANS_ITERS} Lloyd iterations), lag={LAG}, "
-                                   "row-normalised T", "frames_per_gpu": n, "features": N_FEATURES,
-                       "tica_dim": TICA_DIM, "k": K_STATES, "lag": LAG, "kmeans_iters": KMEANS_ITERS,
-                       "parallelism": f"shards{world}",
-                       "exchange": ("rccl" if os.environ.get("BENCH_BACKEND", "nccl") == "nccl" else "gloo") if multi
-                       else None},
-            "roofline": {"kernel": "kmeans_mfma_kernel<double,3,2,1024,true,true,false> (assign + accumulate)", "bound": "mfma",
-                         "achieved": achieved_tf, "peak": FP64_MFMA_PEAK_TF, "unit": "TFLOP/s",
-                         "frac": achieved_tf / FP64_MFMA_PEAK_TF,
-                         "traffic": KMEANS_ACCUM_TRAFFIC_BYTES if n == N_FRAMES else None,
-                         "traffic_unit": "bytes per launch (rocprofv3 PMC, profiles/r01_pmc_hbm.md)",
-                         "launch_ms": acc_ms_avg, "launches_timed": len(acc_ms),
-                         "algorithmic_flops_per_launch": flops_per_launch},
+            "config": {"workload": workload, "name": args.config, "frames_per_gpu": n, "features": F, "tica_dim": d, "k": k,
+                       "lag": lag, "kmeans_iters": iters, "parallelism": f"shards{world}",
+                       "exchange": ({"rccl": "rccl (C ABI)", "torch": "torch.distributed " + os.environ.get("BENCH_BACKEND", "nccl")}
+                                    [comm_kind] if multi else None),
+                       "collectives_per_step": (n_coll / args.steps if multi else 0)},
+            "roofline": roofline,
+            "stages_ms": stages,
         }
         # ---- parity of this very run against the CPU oracle (outside the timed region) ----
         parity = {}
         try:
             from oracle import cport, npport
 
-            counts = msm.buf["counts"].view((K_STATES, K_STATES)).to_host()
-            pairs = int(msm.buf["counts"].view((1,), offset_elems=K_STATES * K_STATES).to_host()[0])
+            L = len(c["lags"]) if c.get("lags") else 1
+            li = list(c["lags"]).index(lag) if c.get("lags") and lag in c["lags"] else 0
+            counts_all = msm.buf["counts"].view((L, k, k)).to_host()
+            pairs_all = msm.buf["counts"].view((L,), offset_elems=L * k * k).to_host()
+            counts = counts_all[li]
             labels = msm.labels.to_host()
+            centers = msm.buf["centers"].to_host()
+            nchk = min(n, 250_000)      # the oracle's assignment is a scalar loop: a quarter of a million frames
+            Yh = (msm.Y.view((nchk, dc)) if True else msm.Y).to_host().astype(np.float64)
+            parity["labels_bit_exact_given_centres"] = bool(np.array_equal(labels[:nchk], cport.kmeans_assign(Yh, centers)))
+            parity["labels_checked"] = nchk
             if world == 1:
-                want, pw = cport.count_transitions(labels, K_STATES, LAG)
-                parity["counts_bit_exact"] = bool(np.array_equal(counts, want) and pairs == pw)
-                want_lab = cport.kmeans_assign(msm.Y.to_host(), msm.buf["centers"].to_host())
-                parity["labels_bit_exact_given_centres"] = bool(np.array_equal(labels, want_lab))
+                ok = True
+                for i in range(L):
+                    want, pw = cport.count_transitions(labels, k, int(c["lags"][i]) if c.get("lags") else lag)
+                    ok = ok and bool(np.array_equal(counts_all[i], want)) and int(pairs_all[i]) == pw
+                parity["counts_bit_exact"] = ok
             tm = eng.transition_matrix(eng.to_device(counts), mode=1)
-            spec = eng.spectrum(tm["T"], n=tm["n_active"], n_its=5, lags=[float(LAG)], allow_unconverged=True)
-            ev_ref, ts_ref = npport.its_from_counts(counts, LAG, 5)
-            ok = np.isfinite(ts_ref)
-            parity["its_rel_err"] = float(np.max(np.abs(spec["its_ts"][0][ok] - ts_ref[ok]) / ts_ref[ok]))
+            spec = eng.spectrum(tm["T"], n=tm["n_active"], n_its=5, lags=[float(c["lags"][li] if c.get("lags") else lag)],
+                                allow_unconverged=True)
+            ev_ref, ts_ref = npport.its_from_counts(counts, int(c["lags"][li] if c.get("lags") else lag), 5)
+            okm = np.isfinite(ts_ref)
+            parity["its_rel_err"] = float(np.max(np.abs(spec["its_ts"][0][okm] - ts_ref[okm]) / ts_ref[okm]))
             parity["its_timescales_frames"] = spec["its_ts"][0].tolist()
             parity["its_residual"] = float(spec["residual"][0])
-            parity["tica_eigenvalues"] = msm.eig.to_host()[:TICA_DIM].tolist()
-            parity["tica_rank"] = int(msm.rank_d.to_host()[0])
-            if multi and n * world <= 2_000_000:
+            if d:
+                parity["tica_eigenvalues"] = msm.eig.to_host()[:d].tolist()
+                parity["tica_rank"] = int(msm.rank_d.to_host()[0])
+            if filtered:
+                parity["kmeans_filter_scanned_frames_per_pass"] = eng.kmeans_filter_scanned() / max(
+                    1, (args.steps + args.warmup) * (iters + 1))
+            if d and multi and n * world <= 2_000_000:
                 # rank 0 regenerates every shard (seeded) and checks the all-reduced TICA against the
                 # oracle on the list of shards (pairs never cross a shard)
-                shards = [npport.preprocess(np.vstack([_gen.correlated_series(n, N_FEATURES, seed=1000 + r)
-                                                       for r in range(world)]), scale=True)]
-                parts = [shards[0][r * n:(r + 1) * n] for r in range(world)]
-                ref = npport.tica_fit(parts, LAG, dim=TICA_DIM)
+                allx = npport.preprocess(np.vstack([_gen.correlated_series(n, F, seed=1000 + r) for r in range(world)]),
+                                         scale=True)
+                ref = npport.tica_fit([allx[r * n:(r + 1) * n] for r in range(world)], lag, dim=d)
                 got = np.asarray(parity["tica_eigenvalues"])
-                m = min(2 * world, TICA_DIM)  # the resolved slow modes (2 per independently mixed shard)
+                m = min(2 * world, d)  # the resolved slow modes (2 per independently mixed shard)
                 parity["tica_eig_rel_err"] = float(np.max(np.abs(got[:m] - ref["eigenvalues"][:m])
                                                           / np.abs(ref["eigenvalues"][:m])))
                 parity["tica_rank_oracle"] = int(ref["rank"])
         except Exception as exc:  # parity reporting must not hide the throughput line
             parity["error"] = repr(exc)
         out["parity"] = parity
-        out["from_host"] = from_host
-        if not multi and not args.no_cpu_baseline:
-            cb = cpu_baseline(X)
+
+        extra = (not multi) and (not args.no_extra_legs) and args.config == "c3" and X is not None
+        # from-host pass: the same step with the shard uploaded from pageable host
+        # memory inside the clock -- reported beside `value`, never as it
+        if not multi and X is not None:
+            eng.sync()
+            t1 = time.perf_counter()
+            xd2 = eng.to_device(X)
+            eng.sync()
+            h2d = time.perf_counter() - t1
+            msm.x = xd2
+            msm.step()
+            eng.sync()
+            tot = time.perf_counter() - t1
+            msm.x = xd
+            del xd2
+            out["from_host"] = {"value": n / tot, "unit": "frames/s", "h2d_ms": h2d * 1e3, "step_ms": (tot - h2d) * 1e3,
+                                "h2d_GBps": X.nbytes / h2d / 1e9, "note": "one pageable-memory upload + one step"}
+        if not multi and not args.no_cpu_baseline and X is not None and d:
+            cb = cpu_baseline(X, c)
             ref_eig = np.asarray(cb.pop("tica_eigenvalues"))
+            Yz = cb.pop("_Yz")
             got = np.asarray(parity.get("tica_eigenvalues", ref_eig))
             out["parity"]["tica_eig_rel_err"] = float(np.max(np.abs(got - ref_eig) / np.abs(ref_eig)))
             out["cpu_baseline"] = cb
-            if args.cpu_single_thread:
-                from threadpoolctl import threadpool_limits
+            from threadpoolctl import threadpool_limits
 
-                with threadpool_limits(limits=1):
-                    cb1 = cpu_baseline(X)
-                cb1.pop("tica_eigenvalues", None)
-                cb1["cores"] = 1
-                out["cpu_baseline_1thread"] = cb1
-        else:
+            with threadpool_limits(limits=1):
+                cb1 = cpu_baseline(X, c)
+            for key in ("tica_eigenvalues", "_Yz"):
+                cb1.pop(key, None)
+            cb1["cores"] = 1
+            out["cpu_baseline_1thread"] = cb1
+            # what the fast k-means buys: the device's 10 Lloyd iterations and the CPU branch (MiniBatchKMeans) on
+            # the SAME whitened coordinates, inertia = sum of squared distances to the assigned centre
+            try:
+                yz = eng.to_device(np.ascontiguousarray(Yz))
+                cen, st = eng.kmeans_fit(yz, k, seed=0, max_iter=iters, tol2=0.0)
+                md = eng.empty((n,), np.float64)
+                eng.kmeans_assign(yz, cen, mindist=md)
+                dev_inertia = float(eng.sum_f64(md).to_host()[0])
+                cen100, _ = eng.kmeans_fit(yz, k, seed=0, max_iter=100, tol2=1e-4 * dc)
+                eng.kmeans_assign(yz, cen100, mindist=md)
+                out["kmeans_quality"] = {
+                    "space": "TICA coordinates whitened as the reference's discretizer does (z-score, ddof = 1)",
+                    "inertia_device_10_lloyd": dev_inertia,
+                    "inertia_device_to_tolerance": float(eng.sum_f64(md).to_host()[0]),
+                    "inertia_cpu_baseline_minibatch": cb["inertia_whitened"],
+                    "ratio_device_over_cpu": dev_inertia / cb["inertia_whitened"]}
+                del yz, md
+            except Exception as exc:
+                out["kmeans_quality"] = {"error": repr(exc)}
+        elif rank == 0:
             out["cpu_baseline"] = None
+        if extra:
+            try:
+                out["featurize"] = featurize_legs(eng, c)
+            except Exception as exc:
+                out["featurize"] = {"error": repr(exc)}
+            try:
+                out["operator_api"] = operator_api_leg(X, c)
+            except Exception as exc:
+                out["operator_api"] = {"error": repr(exc)}
         print(json.dumps(out), flush=True)
     if multi:
-        dist.barrier()
-        dist.destroy_process_group()
+        barrier()
+        if comm_kind == "torch":
+            dist.destroy_process_group()
+        else:
+            comm.close()
 
 
 if __name__ == "__main__":

@@ -601,6 +601,40 @@ msm_status msm_first_occurrence(msm_ctx* ctx, const int32_t* d_flat, int64_t n, 
 msm_status msm_relabel(msm_ctx* ctx, const int32_t* d_flat, int64_t n, const int32_t* d_map, int n_cells,
                        int32_t* d_labels);
 
+/* ------------------------------------------------------------------ */
+/* exchange steps of the sharded path (RCCL over xGMI)                  */
+/* ------------------------------------------------------------------ */
+
+/* One process per GPU, one trajectory shard per process (the reference has no
+ * multi-device code: lag pairs never cross a shard -- S/analysis/discretize.py:625-632 segments,
+ * S/markov_state_model/_features.py:216-227 per-trajectory frame dropping -- so only the SMALL
+ * per-shard results are summed).  The collectives run on the context's stream, in place, on device
+ * buffers; librccl is dlopen'ed by the first msm_comm_unique_id / msm_comm_init.
+ *
+ *   msm_comm_unique_id     rank 0 draws the 128-byte RCCL id; the caller carries it to the other ranks
+ *                          (file, environment, any store: pmarlo_amd/dist.py uses a file)
+ *   msm_comm_init          collective over `world` processes (ncclCommInitRank)
+ *   msm_allreduce_i64      exact integer sum: k-means member sums / counts, transition counts, the
+ *                          batched L x k x k lag-scan counts (one call)
+ *   msm_allreduce_f64      fp64 sum in RANK ORDER (all-gather + fixed-order add): moment blocks; the same
+ *                          bits on every rank and for every algorithm RCCL may choose
+ *   msm_allreduce_min_f64  / _max_f64: the fixed-point scale of the Lloyd sums; timing maxima
+ *   msm_broadcast          bytes from `root`: the shared shift vector, the initial centres
+ *   msm_comm_info          rank, world and the number of collectives issued so far
+ *   msm_rcp_f64            dst[i] = 1 / src[i] on the stream (2^-e after the MIN of 2^e: exact) */
+typedef struct msm_comm msm_comm;
+#define MSM_COMM_ID_BYTES 128
+msm_status msm_comm_unique_id(void* out_id, size_t bytes);
+msm_status msm_comm_init(msm_ctx* ctx, int rank, int world, const void* id, size_t id_bytes, msm_comm** out);
+void msm_comm_destroy(msm_comm* comm);
+msm_status msm_comm_info(msm_comm* comm, int* rank, int* world, uint64_t* n_collectives);
+msm_status msm_allreduce_i64(msm_comm* comm, int64_t* d_buf, size_t count);
+msm_status msm_allreduce_f64(msm_comm* comm, double* d_buf, size_t count);
+msm_status msm_allreduce_min_f64(msm_comm* comm, double* d_buf, size_t count);
+msm_status msm_allreduce_max_f64(msm_comm* comm, double* d_buf, size_t count);
+msm_status msm_broadcast(msm_comm* comm, void* d_buf, size_t bytes, int root);
+msm_status msm_rcp_f64(msm_ctx* ctx, const double* d_src, size_t n, double* d_dst);
+
 #ifdef __cplusplus
 }
 #endif

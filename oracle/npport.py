@@ -162,15 +162,22 @@ def tica_fit(Xs: Sequence[np.ndarray], lag: int, dim: int | None = None, epsilon
     C00 has negative eigenvalues), canonical signs (largest |component| positive);
     eigh of L' C0t L; sort descending by magnitude; eigenvectors R = L R', canonical
     signs; kinetic_map scaling multiplies eigenvector i by eigenvalue i.  PARITY UNPINNED."""
-    m = lagged_moments(Xs, lag)
+    return tica_from_moments(lagged_moments(Xs, lag), dim=dim, epsilon=epsilon, scaling=scaling)
+
+
+def tica_from_moments(m, dim=None, epsilon: float = 1e-6, scaling: str | None = "kinetic_map", scale=None):
+    """The solve of tica_fit from raw moments (the form shards exchange).  `scale` (per-feature divisor):
+    covariances of the data divided by it, i.e. of the standardised features."""
     T = m["T"]
     if T == 0:
         raise ValueError("no lagged pairs")
     w = 2.0 * T
-    mean = (m["sx"] + m["sy"]) / w
-    C00 = m["Mxx"] / w - np.outer(mean, mean)
+    isc = np.ones_like(m["sx"]) if scale is None else 1.0 / np.asarray(scale, np.float64)
+    ss = np.outer(isc, isc)
+    mean = (m["sx"] + m["sy"]) / w * isc
+    C00 = m["Mxx"] / w * ss - np.outer(mean, mean)
     Mxy = m["Mxy_half"] + m["Mxy_half"].T
-    C0t = Mxy / w - np.outer(mean, mean)
+    C0t = Mxy / w * ss - np.outer(mean, mean)
     C00 = 0.5 * (C00 + C00.T)
     C0t = 0.5 * (C0t + C0t.T)
     s, V = np.linalg.eigh(C00)

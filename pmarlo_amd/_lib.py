@@ -78,6 +78,16 @@ _PROTOTYPES: dict[str, tuple] = {
         _i32, [_vp, _vp, _i32, _i64, _i32, _i64, _vp, _vp, _i32, C.c_uint64, _i32, _f64, _f64, _vp, _vp, _i32]),
     "msm_kmeans_accumulate": (_i32, [_vp, _vp, _i32, _i64, _i32, _i64, _vp, _i32, _vp, _vp, _vp, _vp, _vp]),
     "msm_kmeans_update": (_i32, [_vp, _vp, _vp, _i32, _i32, _vp, _vp, _i32]),
+    "msm_comm_unique_id": (_i32, [_vp, _sz]),
+    "msm_comm_init": (_i32, [_vp, _i32, _i32, _vp, _sz, _pp]),
+    "msm_comm_destroy": (None, [_vp]),
+    "msm_comm_info": (_i32, [_vp, C.POINTER(_i32), C.POINTER(_i32), C.POINTER(C.c_uint64)]),
+    "msm_allreduce_i64": (_i32, [_vp, _vp, _sz]),
+    "msm_allreduce_f64": (_i32, [_vp, _vp, _sz]),
+    "msm_allreduce_min_f64": (_i32, [_vp, _vp, _sz]),
+    "msm_allreduce_max_f64": (_i32, [_vp, _vp, _sz]),
+    "msm_broadcast": (_i32, [_vp, _vp, _sz, _i32]),
+    "msm_rcp_f64": (_i32, [_vp, _vp, _sz, _vp]),
     "msm_kmeans_image_bytes": (_i32, [_i64, _i32, C.POINTER(_sz)]),
     "msm_kmeans_pack": (_i32, [_vp, _vp, _i32, _i64, _i32, _i64, _vp, _vp, _vp]),
     "msm_kmeans_assign_packed": (_i32, [_vp, _vp, _i32, _i64, _i32, _i64, _vp, _i32, _vp, _vp, _vp, _vp, _vp]),

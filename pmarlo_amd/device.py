@@ -260,6 +260,14 @@ class Engine:
         self.sync()  # index tables are freed on return
         return out
 
+    def featurize_distances_into(self, xyz: DeviceArray, pairs: DeviceArray, out: DeviceArray, col0: int = 0) -> DeviceArray:
+        """Pair distances with a device-resident int32 [P, 2] index table into columns col0.. of `out` (float32
+        [n, ld]); no upload, no sync: the form a timed step uses."""
+        n, A, _ = xyz.shape
+        check(lib.msm_featurize_distances(self.handle, xyz.ptr, n, A, pairs.ptr, pairs.shape[0], out.ptr, out.shape[1],
+                                          int(col0)), self.handle)
+        return out
+
     # -- transition counts ----------------------------------------------------
     @staticmethod
     def _seg_ptrs(starts: np.ndarray, stops: np.ndarray):
@@ -400,12 +408,15 @@ class Engine:
         return out
 
     def tica_solve(self, moments: DeviceArray, F: int, *, scale: DeviceArray | None = None,
-                   epsilon: float = 1e-6, kinetic_map: bool = True):
-        """-> (eigvals [F], coeffs [F,F], mean [F], rank int32[1]) on the device."""
-        eig = self.empty((F,), np.float64)
-        W = self.empty((F, F), np.float64)
-        mean = self.empty((F,), np.float64)
-        rank = self.empty((1,), np.int32)
+                   epsilon: float = 1e-6, kinetic_map: bool = True, out=None):
+        """-> (eigvals [F], coeffs [F,F], mean [F], rank int32[1]) on the device (`out`: the same four, preallocated)."""
+        if out is not None:
+            eig, W, mean, rank = out
+        else:
+            eig = self.empty((F,), np.float64)
+            W = self.empty((F, F), np.float64)
+            mean = self.empty((F,), np.float64)
+            rank = self.empty((1,), np.int32)
         check(lib.msm_tica_solve(self.handle, moments.ptr, scale.ptr if scale is not None else None, F,
                                  float(epsilon), int(bool(kinetic_map)), eig.ptr, W.ptr, mean.ptr, rank.ptr),
               self.handle)
@@ -556,6 +567,15 @@ class Engine:
                                             rowsum.ptr, None), self.handle)
             out.update(active=active, inv_map=inv, n_active=na)
         return out
+
+    def row_normalise_into(self, counts: DeviceArray, T: DeviceArray, rowsum: DeviceArray, diag_mass: DeviceArray):
+        """T = counts / rowsum (zero rows stay zero), trace(T)/k: msm_transition_matrix mode 0 into given arrays."""
+        k = counts.shape[0]
+        check(lib.msm_transition_matrix(self.handle, counts.ptr, int(counts.dtype == np.float64), k, 0, 0.0, 0.0,
+                                        T.ptr, None, None, None, rowsum.ptr, diag_mass.ptr), self.handle)
+
+    def rcp(self, src: DeviceArray, dst: DeviceArray) -> None:
+        check(lib.msm_rcp_f64(self.handle, src.ptr, src.size, dst.ptr), self.handle)
 
     def embed_full(self, T_active: DeviceArray, inv_map: DeviceArray, pi_active: DeviceArray | None = None):
         k = T_active.shape[0]

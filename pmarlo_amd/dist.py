@@ -1,37 +1,46 @@
 """One trajectory shard per GPU: the hot path with all-reduce of the SMALL buffers only.
 
 Shards are independent trajectory segments (lag pairs never cross a shard),
-so the big arrays (features, projected coordinates, labels) never leave their GPU.  What is
-exchanged, by plain summation over RCCL/xGMI (``torch.distributed``, backend "nccl"):
+so the big arrays (coordinates, features, projected coordinates, labels) never leave their GPU.
+What is exchanged, by plain summation over RCCL / xGMI:
 
   exchange                      payload                         when
   lagged moments + the          2F^2 + 2F + 1 + 3F f64          once (one buffer, one collective)
     standardisation sums
   k-means fixed-point scale     1 f64 (MIN) + centres bcast     once
   k-means member sums / counts  k*d + k int64 (exact)           per Lloyd iteration
-  transition counts             k^2 int64 (exact)               once
+  transition counts             k^2 int64 (exact), or the       once (one collective for a whole
+                                L k^2 + L block of a lag scan     lag scan)
 
-Integer payloads make the result independent of the number of shards bit for bit; the fp64
-moment sums are gathered and added in rank order (bit-identical on every rank, independent of the
-collective's schedule).  With ``comm=None`` the
-same code runs on a single GPU (bench.py at N=1, tests).
+i.e. 4 + kmeans_iters collectives per step with TICA, 3 + kmeans_iters without (`ShardedMSM.collectives_per_step`).
+Integer payloads make the result independent of the number of shards bit for bit; the fp64 moment sums are
+gathered and added in rank order (bit-identical on every rank, independent of the collective's schedule).
+
+Two transports implement `Comm`:
+  NativeComm   RCCL through the C ABI (msm_comm_init / msm_allreduce_* / msm_broadcast, include/msmhip.h) on the
+               engine's stream; the 128-byte RCCL id travels through a file (`bootstrap_id`).  No torch involved.
+  TorchComm    torch.distributed collectives on torch tensors (the gloo tests on CPU; "nccl" also works).
+With ``comm=None`` the same code runs on a single GPU (bench.py at N = 1, tests).
 """
 
 from __future__ import annotations
 
+import ctypes as C
+import os
+import time
 from dataclasses import dataclass
+from pathlib import Path
 
 import numpy as np
 
 from .device import DeviceArray, Engine
 
-__all__ = ["Comm", "ShardedMSM", "ShardConfig", "exchange_shapes", "exchange_aliases", "TorchComm",
-           "torch_exchange_buffers"]
+__all__ = ["Comm", "NativeComm", "TorchComm", "ShardedMSM", "ShardConfig", "exchange_shapes", "exchange_aliases",
+           "torch_exchange_buffers", "bootstrap_id"]
 
 
 class Comm:
-    """Reduction interface over device buffers.  ``TorchComm`` wraps torch.distributed; the
-    buffers it is given are views of torch tensors (see ``ShardedMSM.alloc``)."""
+    """Reduction interface over NAMED exchange buffers (exchange_shapes / exchange_aliases)."""
 
     world = 1
     rank = 0
@@ -41,6 +50,97 @@ class Comm:
     def allreduce_max(self, name: str) -> None: ...
     def broadcast(self, name: str, src: int = 0) -> None: ...
     def reciprocal(self, dst: str, src: str) -> None: ...
+
+
+def bootstrap_id(rank: int, world: int, path: str | os.PathLike | None = None, timeout: float = 300.0) -> bytes:
+    """Carry rank 0's RCCL unique id to the other ranks of this launch through a file.
+
+    The default name is keyed by MASTER_PORT and the parent process id (the launcher that started every rank
+    of the node), so concurrent or earlier launches do not collide; MSM_COMM_ID_FILE overrides it."""
+    from ._lib import check, lib
+
+    if path is None:
+        path = os.environ.get("MSM_COMM_ID_FILE") or (
+            f"/tmp/msm_comm_{os.environ.get('MASTER_PORT', '0')}_{os.getppid()}.id")
+    path = Path(path)
+    if rank == 0:
+        buf = (C.c_ubyte * 128)()
+        check(lib.msm_comm_unique_id(buf, 128), None)
+        tmp = path.with_suffix(f".tmp{os.getpid()}")
+        tmp.write_bytes(bytes(buf))
+        os.replace(tmp, path)
+        return bytes(buf)
+    t0 = time.monotonic()
+    while True:
+        try:
+            data = path.read_bytes()
+            if len(data) == 128:
+                return data
+        except FileNotFoundError:
+            pass
+        if time.monotonic() - t0 > timeout:
+            raise TimeoutError(f"rank {rank}: no RCCL id at {path} after {timeout:.0f} s")
+        time.sleep(0.01)
+
+
+class NativeComm(Comm):
+    """RCCL collectives through the C ABI, on the engine's stream, in place on DeviceArrays."""
+
+    def __init__(self, engine: Engine, bufs: dict[str, DeviceArray], rank: int, world: int, uid: bytes,
+                 id_file: str | os.PathLike | None = None):
+        from ._lib import check, lib
+
+        self.eng, self.b, self.rank, self.world = engine, bufs, int(rank), int(world)
+        self._lib, self._check = lib, check
+        handle = C.c_void_p()
+        idbuf = (C.c_ubyte * 128).from_buffer_copy(uid)
+        check(lib.msm_comm_init(engine.handle, self.rank, self.world, idbuf, 128, C.byref(handle)), engine.handle)
+        self.handle = handle
+        self._id_file = id_file
+
+    @classmethod
+    def from_env(cls, engine: Engine, bufs: dict[str, DeviceArray]) -> "NativeComm":
+        rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+        return cls(engine, bufs, rank, world, bootstrap_id(rank, world))
+
+    def close(self) -> None:
+        if getattr(self, "handle", None):
+            self._lib.msm_comm_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):  # pragma: no cover
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def n_collectives(self) -> int:
+        n = C.c_uint64(0)
+        self._check(self._lib.msm_comm_info(self.handle, None, None, C.byref(n)), self.eng.handle)
+        return int(n.value)
+
+    def allreduce_sum(self, name):
+        a = self.b[name]
+        fn = self._lib.msm_allreduce_i64 if a.dtype == np.int64 else self._lib.msm_allreduce_f64
+        if a.dtype not in (np.dtype(np.int64), np.dtype(np.float64)):
+            raise TypeError(f"exchange buffer {name!r} must be int64 or float64")
+        self._check(fn(self.handle, a.ptr, a.size), self.eng.handle)
+
+    def allreduce_min(self, name):
+        a = self.b[name]
+        self._check(self._lib.msm_allreduce_min_f64(self.handle, a.ptr, a.size), self.eng.handle)
+
+    def allreduce_max(self, name):
+        a = self.b[name]
+        self._check(self._lib.msm_allreduce_max_f64(self.handle, a.ptr, a.size), self.eng.handle)
+
+    def broadcast(self, name, src=0):
+        a = self.b[name]
+        self._check(self._lib.msm_broadcast(self.handle, a.ptr, a.nbytes, int(src)), self.eng.handle)
+
+    def reciprocal(self, dst, src):
+        self.eng.rcp(self.b[src], self.b[dst])
 
 
 class TorchComm(Comm):
@@ -55,9 +155,11 @@ class TorchComm(Comm):
         self.rank = dist.get_rank()
         self._gather: dict = {}
         self._into_tensor = dist.get_backend() == "nccl"
+        self.n_collectives = 0
 
     def allreduce_sum(self, name):
         t = self.t[name]
+        self.n_collectives += 1
         if not t.dtype.is_floating_point:
             # integer sums commute: any reduction schedule gives the same bits
             self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
@@ -78,15 +180,21 @@ class TorchComm(Comm):
         else:
             self.dist.all_gather([buf[r] for r in range(self.world)], t)
         # fixed-order sum over the rank axis: one kernel, no atomics, the same bits on every rank
-        torch.sum(buf, dim=0, out=t)
+        acc = buf[0].clone()
+        for r in range(1, self.world):
+            acc += buf[r]
+        t.copy_(acc)
 
     def allreduce_min(self, name):
+        self.n_collectives += 1
         self.dist.all_reduce(self.t[name], op=self.dist.ReduceOp.MIN)
 
     def allreduce_max(self, name):
+        self.n_collectives += 1
         self.dist.all_reduce(self.t[name], op=self.dist.ReduceOp.MAX)
 
     def broadcast(self, name, src=0):
+        self.n_collectives += 1
         self.dist.broadcast(self.t[name], src=src)
 
     def reciprocal(self, dst, src):
@@ -100,17 +208,25 @@ class TorchComm(Comm):
 class ShardConfig:
     n_frames: int        # frames of THIS shard
     n_features: int
-    tica_dim: int
+    tica_dim: int        # 0: no TICA, cluster in the feature space itself (C4 / C5 of BASELINE.json)
     k: int
     lag: int
     kmeans_iters: int = 10
     seed: int = 0
     n_total: int | None = None   # frames over all shards (defaults to n_frames * world)
+    lags: tuple | None = None    # lag scan: count matrices for all these lags in one pass, one collective
+    n_atoms: int = 0             # > 0: the shard is xyz float32 [n, n_atoms, 3]; features = pair distances
+    pairs: np.ndarray | None = None   # int32 [n_features, 2] atom pairs of the featurize front stage
+
+    @property
+    def cluster_dim(self) -> int:
+        return self.tica_dim if self.tica_dim > 0 else self.n_features
 
 
 def exchange_shapes(cfg: ShardConfig) -> dict[str, tuple[tuple[int, ...], str]]:
     """name -> (shape, dtype) of every buffer that crosses the interconnect."""
-    F, d, k = cfg.n_features, cfg.tica_dim, cfg.k
+    F, d, k = cfg.n_features, cfg.cluster_dim, cfg.k
+    L = len(cfg.lags) if cfg.lags else 1
     return {
         "shift": ((F,), "float64"),
         # [lagged moments 2F^2 + 2F + 1 | standardisation sums 3F]: both are raw sums about the shared shift
@@ -118,16 +234,27 @@ def exchange_shapes(cfg: ShardConfig) -> dict[str, tuple[tuple[int, ...], str]]:
         "fit_state": ((8,), "float64"),
         "centers": ((k, d), "float64"),
         "km_acc": ((k * d + k,), "int64"),
-        "counts": ((k * k + 1,), "int64"),   # the pair count rides at the end: one collective
+        "counts": ((L * k * k + L,), "int64"),   # the pair counts ride at the end: one collective
     }
 
 
+def exchange_aliases(cfg: ShardConfig) -> dict[str, tuple[str, int, int]]:
+    """name -> (parent buffer, first element, length) of the named parts of exchange buffers."""
+    F = cfg.n_features
+    L = 2 * F * F + 2 * F + 1
+    return {"lagged": ("moments", 0, L), "mom_sums": ("moments", L, 3 * F),
+            "fit_scale": ("fit_state", 0, 1), "fit_inv_scale": ("fit_state", 1, 1)}
+
+
 class ShardedMSM:
-    """featurised shard -> TICA -> k-means -> counts -> T, device resident, one step = one pass."""
+    """(xyz ->) features -> (TICA ->) k-means -> counts -> T, device resident, one step = one pass.
+
+    Only `Engine` methods are called (no direct library calls), so a host stand-in engine can drive this very
+    code on CPU (tests/test_dist_gloo.py)."""
 
     def __init__(self, engine: Engine, cfg: ShardConfig, x: DeviceArray, comm: Comm | None = None,
                  shared: dict[str, DeviceArray] | None = None, always_exchange: bool = False):
-        self.eng, self.cfg, self.x = engine, cfg, x
+        self.eng, self.cfg = engine, cfg
         self.comm = comm
         # always_exchange: run every collective even in a group of one (rehearses the RCCL calls on a
         # one-GPU box; a sum / min / broadcast over one rank leaves the buffers bit-identical)
@@ -135,19 +262,33 @@ class ShardedMSM:
         self.world = comm.world if comm else 1
         self.n_total = cfg.n_total if cfg.n_total is not None else cfg.n_frames * self.world
         eng = engine
-        F, d, k, n = cfg.n_features, cfg.tica_dim, cfg.k, cfg.n_frames
+        F, d, k, n = cfg.n_features, cfg.cluster_dim, cfg.k, cfg.n_frames
         self.buf = shared if shared is not None else {
             nm: eng.zeros(shape, np.dtype(dt)) for nm, (shape, dt) in exchange_shapes(cfg).items()}
         b = self.buf
         for name, (parent, first, length) in exchange_aliases(cfg).items():
             if name not in b:
                 b[name] = b[parent].view((length,), offset_elems=first)
-        self.mean, self.scale, self.inv_scale = (eng.empty((F,), np.float64) for _ in range(3))
-        self.eig = eng.empty((F,), np.float64)
-        self.W = eng.empty((F, F), np.float64)
-        self.m2 = eng.empty((F,), np.float64)
-        self.rank_d = eng.empty((1,), np.int32)
-        self.Y = eng.empty((n, d), np.float64)
+        # featurize front stage: xyz stays resident, the feature matrix is rebuilt by every step
+        if cfg.n_atoms > 0:
+            if cfg.pairs is None or len(cfg.pairs) != F:
+                raise ValueError("ShardConfig.pairs must list n_features atom pairs")
+            self.xyz = x
+            self.pairs_d = eng.to_device(np.ascontiguousarray(cfg.pairs, np.int32).reshape(F, 2))
+            self.x = eng.empty((n, F), np.float32)
+            eng.featurize_distances_into(self.xyz, self.pairs_d, self.x)
+        else:
+            self.xyz = None
+            self.x = x
+        if cfg.tica_dim > 0:
+            self.mean, self.scale, self.inv_scale = (eng.empty((F,), np.float64) for _ in range(3))
+            self.eig = eng.empty((F,), np.float64)
+            self.W = eng.empty((F, F), np.float64)
+            self.m2 = eng.empty((F,), np.float64)
+            self.rank_d = eng.empty((1,), np.int32)
+            self.Y = eng.empty((n, d), np.float64)
+        else:
+            self.Y = self.x
         self.labels = eng.empty((n,), np.int32)
         self.T = eng.empty((k, k), np.float64)
         self.rowsum = eng.empty((k,), np.float64)
@@ -159,47 +300,65 @@ class ShardedMSM:
         nbytes = eng.kmeans_image_bytes(n, d)
         self.km_image = eng.empty((nbytes,), np.uint8) if nbytes else None
         self.accum_events: list = []
+        self.stage_events: dict = {}
         self.time_accum = False
-        # one shift vector shared by all shards (row 0 of rank 0's shard) so that the raw
-        # moment sums add across ranks
-        _, first = eng.column_moments_partial(x)
-        check_d2d = first.to_host()
-        b["shift"].copy_from_host(check_d2d)
-        if comm and (comm.world > 1 or self.always_exchange):
-            comm.broadcast("shift", 0)
+        self.time_stages = False
+        if cfg.tica_dim > 0:
+            # one shift vector shared by all shards (row 0 of rank 0's shard) so that the raw
+            # moment sums add across ranks
+            _, first = eng.column_moments_partial(self.x)
+            b["shift"].copy_from_host(first.to_host())
+            if comm and (comm.world > 1 or self.always_exchange):
+                comm.broadcast("shift", 0)
+
+    @property
+    def collectives_per_step(self) -> int:
+        return (4 if self.cfg.tica_dim > 0 else 3) + self.cfg.kmeans_iters
+
+    def _stamp(self, name: str):
+        if self.time_stages:
+            ev = self.eng.event()
+            ev.record()
+            self.stage_events.setdefault(name, []).append(ev)
 
     def step(self) -> None:
-        from ._lib import check, lib
-
         eng, cfg, b, comm = self.eng, self.cfg, self.buf, self.comm
         multi = comm is not None and (comm.world > 1 or self.always_exchange)
-        F, d, k = cfg.n_features, cfg.tica_dim, cfg.k
-        # 1. time-lagged raw moments about the shared shift (fp64 MFMA): the only pass over X before the
-        #    projection -- the standardisation sums follow from them and 2 * lag edge frames
-        eng.lagged_moments(self.x, cfg.lag, b["shift"], assume_finite=True, out=b["lagged"])
-        eng.moments_from_lagged(self.x, cfg.lag, b["shift"], b["lagged"], out=b["mom_sums"])
-        if multi:
-            comm.allreduce_sum("moments")
-        eng.standardise_params(b["mom_sums"], b["shift"], F, float(self.n_total), True,
-                               out=(self.mean, self.scale, self.inv_scale))
-        # 2. TICA solve
-        check(lib.msm_tica_solve(eng.handle, b["lagged"].ptr, self.scale.ptr, F, 1e-6, 1, self.eig.ptr, self.W.ptr,
-                                 self.m2.ptr, self.rank_d.ptr), eng.handle)
-        # 3. projection
-        # max |Y| (the fixed-point scale of the Lloyd sums needs it) falls out of the same pass
-        # (x - shift) / sigma - m2: m2 is the symmetric mean about the SAME shift the moments used
-        eng.project(self.x, b["shift"], self.inv_scale, self.W, d, mean2=self.m2, out=self.Y,
-                    absmax=b["fit_state"].view((1,), offset_elems=2))
+        F, d, k = cfg.n_features, cfg.cluster_dim, cfg.k
+        self._stamp("begin")
+        # 0. featurize: pair distances from the resident coordinates
+        if self.xyz is not None:
+            eng.featurize_distances_into(self.xyz, self.pairs_d, self.x)
+            self._stamp("featurize")
+        if cfg.tica_dim > 0:
+            # 1. time-lagged raw moments about the shared shift (fp64 MFMA): the only pass over X before the
+            #    projection -- the standardisation sums follow from them and 2 * lag edge frames
+            eng.lagged_moments(self.x, cfg.lag, b["shift"], assume_finite=True, out=b["lagged"])
+            eng.moments_from_lagged(self.x, cfg.lag, b["shift"], b["lagged"], out=b["mom_sums"])
+            if multi:
+                comm.allreduce_sum("moments")
+            eng.standardise_params(b["mom_sums"], b["shift"], F, float(self.n_total), True,
+                                   out=(self.mean, self.scale, self.inv_scale))
+            self._stamp("moments")
+            # 2. TICA solve (every rank solves the same F x F problem on identical bits)
+            eng.tica_solve(b["lagged"], F, scale=self.scale, epsilon=1e-6, kinetic_map=True,
+                           out=(self.eig, self.W, self.m2, self.rank_d))
+            self._stamp("tica_solve")
+            # 3. projection; max |Y| (the fixed-point scale of the Lloyd sums needs it) falls out of the same pass
+            # (x - shift) / sigma - m2: m2 is the symmetric mean about the SAME shift the moments used
+            eng.project(self.x, b["shift"], self.inv_scale, self.W, d, mean2=self.m2, out=self.Y,
+                        absmax=b["fit_state"].view((1,), offset_elems=2))
+            self._stamp("project")
         # 4. k-means: fixed number of Lloyd iterations over all frames
-        check(lib.msm_kmeans_fit_begin(eng.handle, self.Y.ptr, 1, cfg.n_frames, d, d, None, None, k, cfg.seed, 1,
-                                       float(self.n_total), 0.0, b["centers"].ptr, b["fit_state"].ptr, 1), eng.handle)
+        eng.kmeans_fit_begin(self.Y, k, seed=cfg.seed, n_total=self.n_total, tol2=0.0, centers=b["centers"],
+                             state=b["fit_state"], absmax_ready=cfg.tica_dim > 0)
         if multi:
             # identical start on every rank: rank 0's centres; the coarsest fixed-point scale
-            # (state = {scale, inv_scale, ...}: MIN of scale, inv_scale follows as MAX)
+            # (state = {scale, inv_scale, ...}: MIN of scale, inv_scale follows as its reciprocal)
             comm.broadcast("centers", 0)
             comm.allreduce_min("fit_scale")
             comm.reciprocal("fit_inv_scale", "fit_scale")   # 2^-e: exact, no second collective
-        check(lib.msm_memset(eng.handle, b["km_acc"].ptr, 0, b["km_acc"].nbytes), eng.handle)
+        b["km_acc"].zero_()
         if self.km_image is not None:
             eng.kmeans_pack(self.Y, image=self.km_image)
         for _ in range(cfg.kmeans_iters):
@@ -215,21 +374,29 @@ class ShardedMSM:
                 comm.allreduce_sum("km_acc")
             eng.kmeans_update(self.km_sums, self.km_counts, b["centers"], b["fit_state"], clear=True)
         eng.kmeans_assign(self.Y, b["centers"], labels=self.labels, image=self.km_image)
-        # 5. lag-tau counts + row-normalised transition matrix
-        eng.count_transitions(self.labels, k, cfg.lag, out=b["counts"].view((k, k)),
-                              pairs=b["counts"].view((1,), offset_elems=k * k))
-        if multi:
-            comm.allreduce_sum("counts")
-        check(lib.msm_transition_matrix(eng.handle, b["counts"].ptr, 0, k, 0, 0.0, 0.0, self.T.ptr, None, None, None,
-                                        self.rowsum.ptr, self.diag.ptr), eng.handle)
+        self._stamp("kmeans")
+        # 5. lag-tau counts (a whole lag scan in one pass and ONE collective) + row-normalised transition matrix
+        if cfg.lags:
+            L = len(cfg.lags)
+            eng.count_transitions_lagscan(self.labels, k, cfg.lags, out=b["counts"].view((L, k, k)),
+                                          pairs=b["counts"].view((L,), offset_elems=L * k * k))
+            if multi:
+                comm.allreduce_sum("counts")
+            # the matrix of the model lag (the first lag of the scan that equals cfg.lag, else the first one)
+            li = list(cfg.lags).index(cfg.lag) if cfg.lag in cfg.lags else 0
+            eng.row_normalise_into(b["counts"].view((k, k), offset_elems=li * k * k), self.T, self.rowsum, self.diag)
+        else:
+            eng.count_transitions(self.labels, k, cfg.lag, out=b["counts"].view((k, k)),
+                                  pairs=b["counts"].view((1,), offset_elems=k * k))
+            if multi:
+                comm.allreduce_sum("counts")
+            eng.row_normalise_into(b["counts"].view((k, k)), self.T, self.rowsum, self.diag)
+        self._stamp("counts")
 
-
-def exchange_aliases(cfg: ShardConfig) -> dict[str, tuple[str, int, int]]:
-    """name -> (parent buffer, first element, length) of the named parts of exchange buffers."""
-    F = cfg.n_features
-    L = 2 * F * F + 2 * F + 1
-    return {"lagged": ("moments", 0, L), "mom_sums": ("moments", L, 3 * F),
-            "fit_scale": ("fit_state", 0, 1), "fit_inv_scale": ("fit_state", 1, 1)}
+    def lagscan_counts(self) -> np.ndarray:
+        """The (all-reduced) count matrices of the lag scan, [L, k, k] int64 on the host."""
+        L, k = len(self.cfg.lags), self.cfg.k
+        return self.buf["counts"].view((L, k, k)).to_host()
 
 
 def torch_exchange_buffers(engine: Engine, cfg: ShardConfig, device) -> tuple[dict, dict]:

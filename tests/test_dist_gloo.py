@@ -1,11 +1,9 @@
-"""N > 1 path on CPU: world_size-2 gloo run of the exchange protocol of pmarlo_amd.dist.
-
-The HIP kernels cannot run here, so each rank computes its shard's partial statistics with the
-CPU oracle (stand-in for the engine), pushes them through the SAME TorchComm collectives and
-exchange buffers the GPU path uses, and the merged result must equal the single-shard result:
-  - moment sums / lagged moments: equal to summation order (fp64)
-  - k-means fixed-point sums / counts and transition counts: bit-exact (int64)
-This is what makes the result independent of the number of GPUs."""
+"""N > 1 path on CPU: two gloo ranks drive the REAL pmarlo_amd.dist.ShardedMSM.step() -- the code bench.py runs for
+N > 1 -- with a host stand-in for the engine (tests/_host_engine.py: numpy + the CPU oracle behind the Engine
+interface) and TorchComm over gloo.  What can only go wrong with more than one rank is what is checked:
+the shared shift broadcast, the single moments collective over the aliased buffers, the rank-ordered fp64 sum,
+the centres broadcast, the MIN of the fixed-point scale and its reciprocal, the int64 member-sum reduction ordered
+against kmeans_update(clear=True), the count reduction (single lag and the batched lag scan)."""
 
 from __future__ import annotations
 
@@ -18,113 +16,149 @@ import pytest
 
 ROOT = Path(__file__).resolve().parents[1]
 
+N, F, D, K, LAG, ITERS = 6000, 8, 3, 12, 5, 4
+LAGS = (1, 2, 5, 9)
 
-def _worker(rank: int, world: int, port: int, out_dir: str) -> None:
+
+def _cfg(rank: int, world: int, mode: str):
+    from pmarlo_amd.dist import ShardConfig
+
+    if mode == "tica":
+        return ShardConfig(n_frames=N, n_features=F, tica_dim=D, k=K, lag=LAG, kmeans_iters=ITERS, seed=3, n_total=N * world)
+    # C4-like: no TICA (cluster in the feature space), lag scan in one collective
+    return ShardConfig(n_frames=N, n_features=F, tica_dim=0, k=K, lag=LAG, kmeans_iters=ITERS, seed=3, n_total=N * world,
+                       lags=LAGS)
+
+
+def _worker(rank: int, world: int, port: int, out_dir: str, mode: str) -> None:
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     sys.path.insert(0, str(ROOT))
     import torch
     import torch.distributed as dist
 
-    from oracle import cport, npport
-    from pmarlo_amd.dist import ShardConfig, TorchComm, exchange_aliases, exchange_shapes
+    from pmarlo_amd.dist import ShardedMSM, TorchComm, exchange_aliases, exchange_shapes
     from tests import _gen
+    from tests._host_engine import HostArray, HostEngine
 
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    n, F, d, k, lag = 6000, 8, 3, 12, 5
-    cfg = ShardConfig(n_frames=n, n_features=F, tica_dim=d, k=k, lag=lag, n_total=n * world)
-    tensors = {nm: torch.zeros(shape, dtype=getattr(torch, dt)) for nm, (shape, dt) in exchange_shapes(cfg).items()}
+    cfg = _cfg(rank, world, mode)
+    # exchange buffers: numpy memory shared by the torch tensors (collectives) and the engine's arrays
+    arrays = {nm: np.zeros(shape, np.dtype(dt)) for nm, (shape, dt) in exchange_shapes(cfg).items()}
+    tensors = {nm: torch.from_numpy(a) for nm, a in arrays.items()}
+    views = {nm: HostArray(a) for nm, a in arrays.items()}
     for name, (parent, first, length) in exchange_aliases(cfg).items():
         tensors[name] = tensors[parent][first:first + length]
+        views[name] = views[parent].view((length,), offset_elems=first)
     comm = TorchComm(tensors)
-    assert comm.world == world and comm.rank == rank
-
-    X = _gen.correlated_series(n, F, seed=1000 + rank).astype(np.float64)
-    # shared shift = row 0 of rank 0
-    if rank == 0:
-        tensors["shift"].copy_(torch.from_numpy(X[0].copy()))
-    comm.broadcast("shift", 0)
-    shift = tensors["shift"].numpy().copy()
-    dlt = X - shift
-    # the step's protocol: lagged moments and standardisation sums about the shared shift, ONE collective
-    tensors["mom_sums"].copy_(torch.from_numpy(np.concatenate([np.full(F, float(n)), dlt.sum(0), (dlt ** 2).sum(0)])))
-    m = npport.lagged_moments([dlt], lag)
-    tensors["lagged"].copy_(torch.from_numpy(np.concatenate([m["Mxx"].ravel(), m["Mxy_half"].ravel(), m["sx"], m["sy"],
-                                                              [float(m["T"])]])))
-    comm.allreduce_sum("moments")
-    s = tensors["mom_sums"].numpy()
-    cnt, s1, s2 = s[:F], s[F:2 * F], s[2 * F:]
-    mean = shift + s1 / cnt
-    sigma = np.sqrt((s2 - s1 * s1 / cnt) / (n * world))
-    # k-means exchange: scale MIN, centres broadcast, int64 sums
-    Y = (X - mean) / sigma
-    Y = Y[:, :d].copy()
-    amax = np.abs(Y).max()
-    e = 61 - int(np.ceil(np.log2(n * world * amax)))
-    tensors["fit_state"][0] = float(np.ldexp(1.0, e))
-    tensors["fit_state"][1] = float(np.ldexp(1.0, -e))
-    comm.allreduce_min("fit_scale")
-    comm.reciprocal("fit_inv_scale", "fit_scale")
-    scale = float(tensors["fit_state"][0])
-    assert float(tensors["fit_state"][1]) * scale == 1.0   # power of two: the reciprocal is exact
-    if rank == 0:
-        tensors["centers"].copy_(torch.from_numpy(Y[:: n // k][:k].copy()))
-    comm.broadcast("centers", 0)
-    centers = tensors["centers"].numpy().copy()
-    lab = cport.kmeans_assign(Y, centers)
-    acc = np.zeros(k * d + k, np.int64)
-    np.add.at(acc[:k * d].reshape(k, d), lab, np.rint(Y * scale).astype(np.int64))
-    acc[k * d:] = np.bincount(lab, minlength=k)
-    tensors["km_acc"].copy_(torch.from_numpy(acc))
-    comm.allreduce_sum("km_acc")
-    c, p = cport.count_transitions(lab, k, lag)
-    tensors["counts"][:k * k].copy_(torch.from_numpy(c.ravel()))
-    tensors["counts"][k * k] = p        # the pair count rides at the end of the counts buffer
-    comm.allreduce_sum("counts")
-    if rank == 0:
-        np.savez(os.path.join(out_dir, "merged.npz"), **{k_: v.numpy() for k_, v in tensors.items()}, mean=mean,
-                 sigma=sigma, scale=scale)
+    eng = HostEngine()
+    X = _gen.correlated_series(N, F, seed=1000 + rank)
+    msm = ShardedMSM(eng, cfg, eng.to_device(X), comm=comm, shared=views)
+    assert msm.collectives_per_step == (4 if mode == "tica" else 3) + ITERS
+    before = comm.n_collectives
+    msm.step()
+    assert comm.n_collectives - before == msm.collectives_per_step
+    msm.step()          # a second step must start from clean accumulators
+    out = {nm: a.copy() for nm, a in arrays.items()}
+    out.update(Y=np.asarray(msm.Y.a, np.float64).copy(), labels=msm.labels.a.copy(), T=msm.T.a.copy())
+    if mode == "tica":
+        out.update(eig=msm.eig.a.copy(), mean=msm.mean.a.copy(), scale=msm.scale.a.copy())
+    np.savez(os.path.join(out_dir, f"rank{rank}.npz"), **out)
     dist.barrier()
     dist.destroy_process_group()
 
 
-def test_two_rank_exchange_equals_single_shard(tmp_path):
+def _run(tmp_path, mode):
     import torch.multiprocessing as mp
 
+    world, port = 2, 29500 + (os.getpid() % 2000) + (0 if mode == "tica" else 1)
+    mp.start_processes(_worker, args=(world, port, str(tmp_path), mode), nprocs=world, join=True, start_method="spawn")
+    return [np.load(tmp_path / f"rank{r}.npz") for r in range(world)]
+
+
+def _replay_lloyd(Ys, centers0, scale, iters):
+    """Lloyd iterations over ALL frames with the engine's fixed-point rule, written independently of dist.py."""
+    from oracle import cport
+
+    c = centers0.copy()
+    k, d = c.shape
+    for _ in range(iters):
+        S = np.zeros((k, d), np.int64)
+        cnt = np.zeros(k, np.int64)
+        for Y in Ys:
+            lab = cport.kmeans_assign(Y, c)
+            np.add.at(S, lab, np.rint(Y * scale).astype(np.int64))
+            cnt += np.bincount(lab, minlength=k)
+        for j in range(k):
+            if cnt[j] > 0:
+                c[j] = S[j].astype(np.float64) * (1.0 / scale) / float(cnt[j])
+    return c
+
+
+def test_two_rank_step_with_tica(tmp_path):
     from oracle import cport, npport
     from tests import _gen
+    from tests._host_engine import HostEngine, _splitmix_u
 
-    world, port = 2, 29500 + (os.getpid() % 2000)
-    mp.start_processes(_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True, start_method="spawn")
-    g = np.load(tmp_path / "merged.npz")
-    n, F, d, k, lag = 6000, 8, 3, 12, 5
-    Xs = [_gen.correlated_series(n, F, seed=1000 + r).astype(np.float64) for r in range(world)]
+    g = _run(tmp_path, "tica")
+    world = 2
+    Xs = [_gen.correlated_series(N, F, seed=1000 + r).astype(np.float64) for r in range(world)]
     Xall = np.vstack(Xs)
-    # standardisation: equals the statistics of the concatenated data
-    np.testing.assert_allclose(g["mean"], Xall.mean(0), rtol=1e-12)
-    np.testing.assert_allclose(g["sigma"], Xall.std(0), rtol=1e-12)
-    # lagged moments: per-shard pairs only (no pair crosses the shard boundary)
-    ref = npport.lagged_moments([X - g["shift"] for X in Xs], lag)
-    lagged = g["lagged"]
-    np.testing.assert_allclose(lagged[:F * F].reshape(F, F), ref["Mxx"], rtol=1e-12, atol=1e-9)
-    np.testing.assert_allclose(lagged[F * F:2 * F * F].reshape(F, F), ref["Mxy_half"], rtol=1e-12, atol=1e-9)
-    assert lagged[-1] == ref["T"] == world * (n - lag)
-    # integer payloads: bit-exact, independent of the number of shards
-    Y = ((Xall - g["mean"]) / g["sigma"])[:, :d].copy()
-    lab = cport.kmeans_assign(Y, g["centers"])
-    acc = np.zeros(k * d + k, np.int64)
-    np.add.at(acc[:k * d].reshape(k, d), lab, np.rint(Y * float(g["scale"])).astype(np.int64))
-    acc[k * d:] = np.bincount(lab, minlength=k)
-    np.testing.assert_array_equal(g["km_acc"], acc)
-    want = sum(cport.count_transitions(lab[r * n:(r + 1) * n], k, lag)[0] for r in range(world))
-    np.testing.assert_array_equal(g["counts"][:k * k].reshape(k, k), want)
-    assert int(g["counts"][k * k]) == world * (n - lag)
-    # scale agreed on by all ranks is the coarsest one
-    amax = max(np.abs(((X - g["mean"]) / g["sigma"])[:, :d]).max() for X in Xs)
-    assert float(g["scale"]) <= np.ldexp(1.0, 61 - int(np.ceil(np.log2(n * world * amax)))) * (1 + 1e-15)
+    # every replicated quantity is bit-identical on the two ranks
+    for key in ("shift", "moments", "centers", "counts", "eig", "T", "mean", "scale"):
+        np.testing.assert_array_equal(g[0][key], g[1][key], err_msg=key)
+    # fit state: slot 2 is the LOCAL max |Y| (never exchanged); scale, 2^-e, shift^2, tol, done, n_iter agree
+    np.testing.assert_array_equal(np.delete(g[0]["fit_state"], 2), np.delete(g[1]["fit_state"], 2))
+    # the shared shift is row 0 of rank 0's shard; standardisation = statistics of the concatenated data
+    np.testing.assert_array_equal(g[0]["shift"], Xs[0][0])
+    np.testing.assert_allclose(g[0]["mean"], Xall.mean(0), rtol=1e-12)
+    np.testing.assert_allclose(g[0]["scale"], Xall.std(0), rtol=1e-12)
+    # TICA on the list of shards (pairs never cross a shard) against the oracle's own formulation
+    Xp = npport.preprocess(Xall, scale=True)
+    model = npport.tica_fit([Xp[r * N:(r + 1) * N] for r in range(world)], LAG, dim=D)
+    np.testing.assert_allclose(g[0]["eig"][:model["rank"]], model["eigenvalues"], rtol=1e-9, atol=1e-12)
+    lag_block = g[0]["moments"][:2 * F * F + 2 * F + 1]
+    assert lag_block[-1] == world * (N - LAG)
+    # k-means: the scale every rank used is the coarsest one; the start is rank 0's stratified draw, on all ranks
+    Ys = [g[r]["Y"] for r in range(world)]
+    amax = [np.abs(Y).max() for Y in Ys]
+    want_scale = min(np.ldexp(1.0, int(np.clip(61 - int(np.ceil(np.log2(N * world * a))), -900, 60))) for a in amax)
+    assert g[0]["fit_state"][0] == want_scale and g[0]["fit_state"][0] * g[0]["fit_state"][1] == 1.0
+    init = np.stack([Ys[0][min(int((j + _splitmix_u(3, j)) * (N / K)), N - 1)] for j in range(K)])
+    np.testing.assert_array_equal(g[0]["centers"], _replay_lloyd(Ys, init, want_scale, ITERS))
+    # labels are the assignment to the final centres; counts are the sum of the per-shard counts, exactly
+    want = np.zeros((K, K), np.int64)
+    for r in range(world):
+        np.testing.assert_array_equal(g[r]["labels"], cport.kmeans_assign(Ys[r], g[0]["centers"]))
+        want += cport.count_transitions(g[r]["labels"], K, LAG)[0]
+    np.testing.assert_array_equal(g[0]["counts"][:K * K].reshape(K, K), want)
+    assert int(g[0]["counts"][K * K]) == world * (N - LAG)
+    np.testing.assert_array_equal(g[0]["T"], npport.normalise_counts(want.astype(np.float64)))
+    assert np.all(g[0]["km_acc"] == 0)      # cleared by the last update: the next step starts clean
+
+
+def test_two_rank_step_without_tica_lag_scan(tmp_path):
+    """BASELINE config 4 shape: clustering in the feature space, ITS lag scan -> ONE L x k x k int64 collective."""
+    from oracle import cport, npport
+
+    g = _run(tmp_path, "lagscan")
+    world, L = 2, len(LAGS)
+    for key in ("centers", "counts", "T"):
+        np.testing.assert_array_equal(g[0][key], g[1][key], err_msg=key)
+    np.testing.assert_array_equal(np.delete(g[0]["fit_state"], 2), np.delete(g[1]["fit_state"], 2))
+    cnt = g[0]["counts"]
+    for i, lag in enumerate(LAGS):
+        want = sum(cport.count_transitions(g[r]["labels"], K, lag)[0] for r in range(world))
+        np.testing.assert_array_equal(cnt[i * K * K:(i + 1) * K * K].reshape(K, K), want)
+        assert int(cnt[L * K * K + i]) == world * (N - lag)
+    li = LAGS.index(LAG)
+    np.testing.assert_array_equal(g[0]["T"], npport.normalise_counts(
+        cnt[li * K * K:(li + 1) * K * K].reshape(K, K).astype(np.float64)))
+    for r in range(world):
+        np.testing.assert_array_equal(g[r]["labels"], cport.kmeans_assign(g[r]["Y"], g[0]["centers"]))
 
 
 def test_exchange_payload_sizes_match_survey():
-    """C3 payloads (F=64, d=10, k=500)."""
+    """C3 payloads (F=64, d=10, k=500) and the C4 lag scan (k=200, L=50: 16 MB)."""
     from pmarlo_amd.dist import ShardConfig, exchange_shapes
 
     sh = exchange_shapes(ShardConfig(n_frames=1_000_000, n_features=64, tica_dim=10, k=500, lag=10))
@@ -132,3 +166,6 @@ def test_exchange_payload_sizes_match_survey():
     assert nbytes["moments"] == (2 * 64 * 64 + 2 * 64 + 1 + 3 * 64) * 8   # ~68 KB: lagged moments + the sums
     assert nbytes["km_acc"] == (500 * 10 + 500) * 8             # 44 KB per Lloyd iteration
     assert nbytes["counts"] == (500 * 500 + 1) * 8              # 2 MB (+ the pair count)
+    sh4 = exchange_shapes(ShardConfig(n_frames=100_000, n_features=45, tica_dim=0, k=200, lag=1, lags=tuple(range(1, 51))))
+    assert int(np.prod(sh4["counts"][0])) * 8 == (50 * 200 * 200 + 50) * 8   # one 16 MB collective
+    assert sh4["centers"][0] == (200, 45)
