@@ -360,6 +360,43 @@ def reversible_its_from_counts(C, lag, n_timescales):
 # featurizer geometry (fp32; S/features/deeptica/ts_feature_extractor.py:423-500,
 # no PBC) and angle post-processing
 # ---------------------------------------------------------------------------
+def reference_quirk_its_from_counts(C, lag, n_timescales):
+    """What ITSMixin._deterministic_its_from_counts (S/markov_state_model/_its.py:742-801) RETURNS, restated with
+    the published deeptime 0.4.5 algorithms it calls (deeptime itself is absent: parity unpinned): "pi" from the
+    row sums of T = 1 (:753-754) makes deeptime's dense reversible branch (eigenvalues_rev: S = sqrt(pi) T / sqrt(pi),
+    numpy.linalg.eigvalsh(S), decreasing magnitude) run eigvalsh on the non-symmetric T, i.e. on its lower triangle."""
+    C = np.asarray(C, dtype=np.float64)
+    n = int(n_timescales)
+    Crev = 0.5 * (C + C.T)
+    row = Crev.sum(axis=1, keepdims=True)
+    T = Crev / np.where(row == 0, 1.0, row)
+    pi = np.maximum(T.sum(axis=1), 1e-300)
+    pi = pi / pi.sum()
+    smu = np.sqrt(pi)
+    S = smu[:, None] * T / smu
+    w = np.linalg.eigvalsh(S)
+    w = w[np.argsort(np.abs(w), kind="stable")[::-1]]
+    k = T.shape[0]
+    k_eval = None if n + 1 > k else n + 1
+    wk = w if k_eval is None else w[:k_eval]
+    slow = np.sort(wk)[::-1][1:1 + n]
+    ev = np.zeros(n)
+    ev[:slow.shape[0]] = np.clip(np.abs(slow), NUMERIC_MIN_POSITIVE, 1.0 - NUMERIC_MIN_POSITIVE)
+    k_times = None if k_eval is None else min(k, n + 1)
+    wt = w if k_times is None else w[:k_times]
+    tsr = np.zeros(wt.shape[0])
+    one = np.isclose(np.abs(wt), 1.0, rtol=0.0, atol=1e-14)
+    tsr[one] = np.inf
+    with np.errstate(divide="ignore"):
+        tsr[~one] = -float(max(1, int(lag))) / np.log(np.abs(wt[~one]))
+    ts = np.full(n, np.nan)
+    cut = tsr[1:1 + n]
+    ts[:cut.shape[0]] = cut
+    with np.errstate(divide="ignore", invalid="ignore"):
+        rates = np.where(np.isfinite(ts), 1.0 / ts, np.nan)
+    return ev, ts, rates
+
+
 def distances(xyz, pairs, eps=1e-12):
     xyz = np.asarray(xyz, dtype=np.float32)
     p = np.asarray(pairs)

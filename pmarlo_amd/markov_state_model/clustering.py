@@ -17,7 +17,14 @@ logger = logging.getLogger("pmarlo")
 
 __all__ = ["ClusteringResult", "cluster_microstates", "silhouette_score"]
 
-_ALLOWED_KW = {"max_iter", "tolerance", "n_init", "init_centers"}
+# keyword arguments of the reference (clustering.py:236-262): what deeptime's estimators take
+_COMMON_KWARGS = frozenset({"max_iter", "metric", "tolerance", "init_strategy", "n_jobs", "initial_centers"})
+_ATTRIBUTE_KWARGS = frozenset({"fixed_seed", "progress"})
+_MINIBATCH_ONLY_KWARGS = frozenset({"batch_size"})
+_SUPPORTED_KWARGS = _COMMON_KWARGS | _ATTRIBUTE_KWARGS | _MINIBATCH_ONLY_KWARGS
+# extensions of this engine: n_init is the reference's own restart count (popped before validation there too);
+# init_centers is the round-1 spelling of initial_centers
+_EXTENSION_KWARGS = frozenset({"n_init", "init_centers"})
 
 
 @dataclass
@@ -104,10 +111,51 @@ def _auto_select_n_states(Y, random_state, *, sample_size, override_n_states, kw
     return int(chosen), f"silhouette={best:.3f}{note}"
 
 
+def _validate_clustering_kwargs(method: str, kwargs: dict) -> None:
+    """clustering.py:246-262: unknown keywords and batch_size with method='kmeans' are TypeErrors."""
+    unsupported = set(kwargs) - _SUPPORTED_KWARGS - _EXTENSION_KWARGS
+    if unsupported:
+        raise TypeError(f"Unsupported clustering parameters for deeptime backend: {sorted(unsupported)}")
+    if method == "kmeans" and any(k in kwargs for k in _MINIBATCH_ONLY_KWARGS):
+        raise TypeError("'batch_size' is only supported when method='minibatchkmeans'.")
+    metric = kwargs.get("metric", "euclidean")
+    if metric not in ("euclidean", None):
+        raise NotImplementedError(f"metric={metric!r}: the device k-means is Euclidean (deeptime's default)")
+
+
+def _resolve_seed(random_state: int | None, kwargs: dict) -> int:
+    """clustering.py:289-304 (_resolve_fixed_seed): an integer fixed_seed is the seed, True is deeptime's fixed
+    seed 42, False / no random_state mean "not fixed" (the engine is deterministic anyway: seed 0)."""
+    if "fixed_seed" in kwargs:
+        fixed = kwargs["fixed_seed"]
+        if isinstance(fixed, bool):
+            return 42 if fixed else 0
+        if isinstance(fixed, (int, np.integer)):
+            return int(fixed)
+        raise TypeError(f"'fixed_seed' must be an integer or boolean, received type {type(fixed)!r}.")
+    return 0 if random_state is None else int(random_state)
+
+
+def _restart_seeds(random_state: int | None, n_init: int) -> list[int | None]:
+    """The reference's seed list for n_init restarts (clustering.py:586-603)."""
+    if n_init == 1:
+        return [random_state]
+    rng = np.random.default_rng(random_state)
+    seeds: list[int | None] = [None if random_state is None else int(random_state)]
+    existing = {s for s in seeds if isinstance(s, int)}
+    while len(seeds) < n_init:
+        cand = int(rng.integers(0, np.iinfo(np.int32).max))
+        if cand in existing:
+            continue
+        seeds.append(cand)
+        existing.add(cand)
+    return seeds
+
+
 def cluster_microstates(
     Y: np.ndarray,
     method: Literal["auto", "minibatchkmeans", "kmeans"] = "auto",
-    n_states: int | Literal["auto"] = 100,
+    n_states: int | Literal["auto"] = "auto",
     random_state: int | None = 42,
     minibatch_threshold: int = 5_000_000,
     *,
@@ -115,52 +163,100 @@ def cluster_microstates(
     auto_n_states_override: int | None = None,
     **kwargs: Any,
 ) -> ClusteringResult:
-    """k-means microstates on the GPU.  ``method`` is accepted for API compatibility: on this
-    engine every size runs full-batch Lloyd (the reference switches to mini-batch above
-    ``minibatch_threshold`` only to bound CPU time).  Labels are densified and centres
-    recomputed as member means exactly as the reference does after its estimator returns."""
+    """k-means microstates on the GPU; same signature, keyword set, errors and result as the reference
+    (S/markov_state_model/clustering.py:395-665).
+
+    ``method`` only decides which keywords are legal: on this engine every size runs full-batch Lloyd (the
+    reference switches to mini-batch above ``minibatch_threshold`` to bound CPU time), so ``batch_size``,
+    ``n_jobs``, ``progress`` and ``init_strategy`` are accepted and have no effect (the start is the engine's
+    seeded stratified draw, or ``initial_centers``).  Labels are densified and centres recomputed as member
+    means as the reference does after its estimator returns (:364-392) -- on the device: member sums come out of
+    one more accumulate pass in exact fixed point, the relabelling is a device gather."""
     Y = np.asarray(Y)
+    if Y.ndim == 2 and Y.shape[0] == 0:
+        logger.info("Empty dataset provided, returning empty clustering result")
+        return ClusteringResult(labels=np.empty((0,), dtype=int), n_states=0)
     if Y.ndim != 2:
         raise ValueError(f"Input must be 2D array, got shape {Y.shape}")
     if Y.shape[1] == 0:
         raise ValueError("Input array must have at least one feature")
-    if Y.shape[0] == 0:
-        return ClusteringResult(labels=np.zeros((0,), dtype=int), n_states=0, rationale="empty input", centers=None)
+    kwargs = dict(kwargs)
+    raw_n_init = kwargs.get("n_init")
+    if raw_n_init is None:
+        n_init = 1
+    else:
+        try:
+            n_init = int(raw_n_init)
+        except (TypeError, ValueError) as exc:
+            raise TypeError("n_init must be provided as an integer when clustering with deeptime") from exc
+        if n_init <= 0:
+            raise ValueError("n_init must be a positive integer when clustering microstates")
+    if n_init > 1 and "fixed_seed" in kwargs:
+        raise ValueError("n_init cannot be combined with fixed_seed; provide only one mechanism "
+                         "for controlling clustering initialisations.")
+    _validate_clustering_kwargs(method, kwargs)
     if method not in ("auto", "minibatchkmeans", "kmeans"):
         raise ValueError(f"Unsupported clustering method: {method}")
-    unknown = set(kwargs) - _ALLOWED_KW
-    if unknown:
-        raise TypeError(f"Unsupported clustering keyword arguments: {sorted(unknown)}")
+    for ignored in ("n_jobs", "progress", "init_strategy", "batch_size"):
+        if ignored in kwargs:
+            logger.debug("cluster_microstates: %s=%r has no effect on the device estimator", ignored, kwargs[ignored])
     rationale = None
     if Y.dtype not in (np.float32, np.float64):
-        Y = Y.astype(np.float64)
-    if n_states == "auto":
+        Y = Y.astype(np.float64)          # float32 / float64 go to the device as they are (the kernels read both)
+    requested = n_states
+    if isinstance(n_states, str):
+        if n_states != "auto":
+            raise ValueError(f"n_states must be an integer or 'auto', got {n_states!r}")
         n_states, rationale = _auto_select_n_states(Y, random_state, sample_size=silhouette_sample_size,
                                                     override_n_states=auto_n_states_override, kwargs=kwargs)
     k = int(n_states)
-    if k < 1:
-        raise ValueError("n_states must be >= 1")
+    if k <= 0:
+        raise ValueError(f"Number of microstates must be a positive integer; received {k}.")
+    chosen = ("minibatchkmeans" if int(Y.shape[0] * Y.shape[1]) > minibatch_threshold else "kmeans") \
+        if method == "auto" else method
+    if "batch_size" in kwargs and chosen != "minibatchkmeans":
+        raise ValueError(f"batch_size was provided but the selected clustering method is '{chosen}'. "
+                         "Specify method='minibatchkmeans' to use mini-batch parameters.")
     if Y.shape[0] < k:
         raise ValueError(f"Cannot create {k} clusters from {Y.shape[0]} samples")
     eng = get_engine()
     pipe = MSMPipeline(eng)
     yd = eng.to_device(np.ascontiguousarray(Y))
-    seed = 0 if random_state is None else int(random_state)
-    n_init = int(kwargs.get("n_init", 1))
     max_iter = int(kwargs.get("max_iter", 100))
     tol = float(kwargs.get("tolerance", 1e-5))
+    init = kwargs.get("initial_centers", kwargs.get("init_centers"))
+    if init is not None:
+        init = np.asarray(init, dtype=np.float64)
+        if init.shape != (k, Y.shape[1]):
+            raise ValueError(f"initial_centers must have shape {(k, Y.shape[1])}, got {init.shape}")
     best = None
-    for r in range(max(1, n_init)):  # restarts keep the lowest inertia (clustering.py:584-629)
-        labels, centers, inertia = _fit_once(pipe, yd, k, seed + r, max_iter, tol, kwargs.get("init_centers"))
+    for it, seed in enumerate(_restart_seeds(random_state, n_init)):  # restarts keep the lowest inertia (:584-629)
+        s = _resolve_seed(seed, kwargs)
+        labels, centers, inertia = _fit_once(pipe, yd, k, s, max_iter, tol, init)
         if best is None or inertia < best[2]:
-            best = (labels, centers, inertia)
-    raw = best[0].to_host()
-    uniq, dense = np.unique(raw, return_inverse=True)
-    n_unique = int(uniq.size)
-    if n_unique < k:
-        logger.warning("Clustering produced %d unique microstates (requested %d)", n_unique, k)
-    Yf = np.asarray(Y, dtype=float)
-    sums = np.zeros((n_unique, Y.shape[1]))
-    np.add.at(sums, dense, Yf)
-    centers = sums / np.bincount(dense, minlength=n_unique)[:, None]
-    return ClusteringResult(labels=dense.astype(int), n_states=n_unique, rationale=rationale, centers=centers)
+            best = (labels, centers, inertia, seed, it)
+    if n_init > 1:
+        logger.info("Selected best clustering from %d initialisations (iteration=%d, seed=%s, inertia=%.6f)", n_init,
+                    best[4], "None" if best[3] is None else int(best[3]), float(best[2]))
+    labels_d, centers_d = best[0], best[1]
+    # ---- densify + member means (_remap_labels_and_compute_inertia :364-392) on the device
+    n, d = Y.shape
+    _, st = eng.kmeans_fit_begin(yd, k, seed=0, n_total=n, tol2=0.0, centers=centers_d, init_centers=False)
+    sums, counts = eng.zeros((k * d,), np.int64), eng.zeros((k,), np.int64)
+    eng.kmeans_accumulate(yd, centers_d, st, sums, counts)
+    cnt = counts.to_host()
+    occupied = np.flatnonzero(cnt > 0)
+    n_unique = int(occupied.size)
+    if n_unique == 0:
+        raise ValueError("Clustering produced zero unique microstates; verify input coverage and CV preprocessing.")
+    inv_scale = float(st.to_host()[1])
+    centers = sums.to_host().reshape(k, d)[occupied].astype(np.float64) * inv_scale / cnt[occupied, None]
+    if n_unique != k:
+        logger.warning("Clustering produced %d unique microstates, expected %d. Proceeding with the observed value; "
+                       "inspect CV spread or adjust the requested microstate count.", n_unique, k)
+        dense_map = np.full(k, -1, np.int32)
+        dense_map[occupied] = np.arange(n_unique, dtype=np.int32)
+        labels_d = eng.relabel(labels_d, dense_map)
+    logger.info("Clustering completed: requested=%s, actual=%d%s", requested, n_unique,
+                f" ({rationale})" if rationale else "")
+    return ClusteringResult(labels=labels_d.to_host().astype(int), n_states=n_unique, rationale=rationale, centers=centers)

@@ -15,11 +15,15 @@ from __future__ import annotations
 
 from typing import Sequence
 
+import logging
+
 import numpy as np
 
 from ..device import get_engine
 from .estimation import _concat_dtrajs
 from .results import ITSResult
+
+logger = logging.getLogger("pmarlo")
 
 __all__ = ["format_lag_window_ps", "safe_timescales", "compute_implied_timescales", "deterministic_its_from_counts", "detect_timescale_plateau",
            "select_lag_from_its",
@@ -138,16 +142,47 @@ def select_lag_from_its(lag_times, timescales, *, min_lag_idx: int = 3, plateau_
     return int(lags[n // 2])
 
 
-def deterministic_its_from_counts(counts: np.ndarray, lag: int, n_timescales: int):
+def deterministic_its_from_counts(counts: np.ndarray, lag: int, n_timescales: int, *, reference_quirk: bool = False):
     """(eigenvalues, timescales, rates) of the symmetrised estimate T = rownorm((C + C') / 2): the fall-back of
-    ITSMixin._deterministic_its_from_counts (S/markov_state_model/_its.py:742-801) in its mathematically
-    intended form -- the reference takes pi from the row sums of T (identically 1), which de-symmetrises
-    deeptime's similarity transform; that quirk is not replicated.  Spectrum on the device."""
+    ITSMixin._deterministic_its_from_counts (S/markov_state_model/_its.py:742-801).
+
+    reference_quirk=False (default) is its mathematically intended form: the spectrum of T (real, T being
+    reversible with pi ~ row sums of C + C'), on the device.
+    reference_quirk=True reproduces what the reference returns.  It takes "pi" from the row sums of T
+    (:753-754), which are identically 1, so deeptime's similarity transform diag(pi)^1/2 T diag(pi)^-1/2 is T
+    itself and its dense reversible branch calls numpy.linalg.eigvalsh on a matrix that is NOT symmetric --
+    LAPACK then reads the lower triangle only.  The quirk's values are therefore the eigenvalues of the symmetric
+    matrix built from the lower triangle of T, ordered by decreasing magnitude (deeptime), the reported
+    eigenvalues re-sorted by decreasing real part (:763) while the timescales keep deeptime's order (:778-787).
+    Solved by msm_eigh (k <= 256)."""
     C = np.asarray(counts, dtype=np.float64)
     n = int(n_timescales)
     ev, ts = np.zeros(n), np.full(n, np.nan)
     k = C.shape[0]
-    if n > 0 and k > 0:
+    if n > 0 and k > 0 and reference_quirk:
+        if k > 256:
+            raise NotImplementedError("reference_quirk=True solves a dense k x k symmetric problem on the device: k <= 256")
+        eng = get_engine()
+        Crev = 0.5 * (C + C.T)
+        row = Crev.sum(axis=1, keepdims=True)
+        T = Crev / np.where(row == 0, 1.0, row)
+        low = np.tril(T)
+        w = eng.eigh(eng.to_device(np.ascontiguousarray(low + np.tril(T, -1).T)), want_vectors=False)[0].to_host()
+        w = w[np.argsort(np.abs(w), kind="stable")[::-1]]            # deeptime: decreasing magnitude
+        k_eval = None if n + 1 > k else n + 1
+        wk = w if k_eval is None else w[:k_eval]
+        slow = np.sort(wk)[::-1][1:1 + n]                              # :763-768: re-sorted by decreasing real part
+        ev[:slow.shape[0]] = np.clip(np.abs(slow), 1e-12, 1.0 - 1e-12)
+        k_times = None if k_eval is None else min(k, n + 1)
+        wt = w if k_times is None else w[:k_times]
+        tsr = np.zeros(wt.shape[0])
+        one = np.isclose(np.abs(wt), 1.0, rtol=0.0, atol=1e-14)        # deeptime timescales_from_eigenvalues
+        tsr[one] = np.inf
+        with np.errstate(divide="ignore"):
+            tsr[~one] = -float(max(1, int(lag))) / np.log(np.abs(wt[~one]))
+        cut = tsr[1:1 + n]
+        ts[:cut.shape[0]] = cut
+    elif n > 0 and k > 0:
         eng = get_engine()
         T = eng.transition_matrix(eng.to_device(np.ascontiguousarray(0.5 * (C + C.T))), mode=0)["T"]
         want = min(n, max(k - 1, 0))
@@ -180,22 +215,38 @@ def compute_implied_timescales(dtrajs: Sequence[np.ndarray], n_states: int, lag_
                                n_timescales: int = 5, *, n_samples: int = 100, ci: float = 0.95,
                                dirichlet_alpha: float = 1e-3, plateau_m: int | None = None,
                                plateau_epsilon: float = 0.1, time_per_frame_ps: float | None = None,
-                               random_state: int | None = None, return_samples: bool = False) -> ITSResult:
+                               random_state: int | None = None, return_samples: bool = False,
+                               effective_frames: int | None = None) -> ITSResult:
     """Lag scan on the device (ITSMixin.compute_implied_timescales, S/markov_state_model/_its.py:137-192):
     batched counts for all lags, one packed transition matrix per lag, n_samples posterior matrices
-    per lag, one batched spectrum solve over lags x samples, median / percentile band on the host."""
+    per lag, one batched spectrum solve over lags x samples, median / percentile band on the host.
+
+    Input rules of _validate_its_inputs (:453-524): no trajectories, or a shortest trajectory with fewer than two
+    frames (an EMPTY trajectory counts: it makes max_valid_lag = -1), give the empty result; lags above
+    min(len) - 1 are dropped; a largest lag >= `effective_frames` (the mixin's attribute of that name) raises.
+    The confidence bands come from independent Dirichlet rows on C_active + alpha (the closed-form posterior of the
+    non-reversible estimator this engine fits), not from deeptime's reversible BayesianMSM sampler: medians and
+    bands differ from the reference's systematically where detailed balance matters."""
     n = int(n_timescales)
     empty = ITSResult(lag_times=np.array([], dtype=int), eigenvalues=np.empty((0, n)),
                       eigenvalues_ci=np.empty((0, n, 2)), timescales=np.empty((0, n)),
                       timescales_ci=np.empty((0, n, 2)), rates=np.empty((0, n)), rates_ci=np.empty((0, n, 2)))
-    lens = [len(d) for d in dtrajs if len(d)]
-    if not lens:
+    if dtrajs is None or len(dtrajs) == 0:
+        logger.warning("No trajectories available for implied timescales")
         return empty
-    max_valid = min(lens) - 1
+    max_valid = min(len(d) for d in dtrajs) - 1           # :476 -- an empty trajectory is not skipped
+    if max_valid < 1:
+        logger.warning("Trajectories too short for implied timescales")
+        return empty
     wanted = DEFAULT_ITS_LAGS if lag_times is None else [int(max(1, v)) for v in lag_times]
-    lags = [int(v) for v in wanted if 1 <= int(v) <= max_valid]  # :476-500
+    if any(int(v) > max_valid for v in wanted):
+        logger.warning("Capping lag times above max_valid_lag=%s", max_valid)
+    lags = [int(v) for v in wanted if 1 <= int(v) <= max_valid]  # :493-500
     if not lags:
+        logger.warning("No valid lag times after capping")
         return empty
+    if effective_frames is not None and effective_frames > 0 and max(lags) >= effective_frames:   # :517-522
+        raise ValueError(f"Maximum lag {max(lags)} exceeds available effective frames {effective_frames}")
     labels, segs = _concat_dtrajs(dtrajs, n_states)
     eng = get_engine()
     k, L = int(n_states), len(lags)

@@ -162,7 +162,7 @@ def test_cluster_microstates_contract(engine):
     assert isinstance(res, ClusteringResult) and res.output_shape == (res.n_states,)
     assert res.labels.shape == (4000,) and res.labels.min() == 0 and res.labels.max() == res.n_states - 1
     for j in range(res.n_states):  # centres are member means (clustering.py:364-392)
-        np.testing.assert_allclose(res.centers[j], Y[res.labels == j].mean(axis=0), rtol=1e-12)
+        np.testing.assert_allclose(res.centers[j], Y[res.labels == j].mean(axis=0), rtol=1e-12, atol=1e-12)
     again = cluster_microstates(Y, n_states=5, random_state=7)
     np.testing.assert_array_equal(res.labels, again.labels)  # determinism under a fixed seed
     with pytest.raises(TypeError):
@@ -171,6 +171,57 @@ def test_cluster_microstates_contract(engine):
         cluster_microstates(Y[:, 0], n_states=5)
     empty = cluster_microstates(np.zeros((0, 3)), n_states=4)
     assert empty.n_states == 0 and empty.labels.size == 0
+
+
+def test_cluster_microstates_takes_the_reference_keywords(engine):
+    """The keyword set of the reference (clustering.py:236-262 _SUPPORTED_KWARGS) with its errors: every valid
+    reference call must be a valid call here."""
+    from pmarlo_amd.markov_state_model import cluster_microstates
+
+    Y, true_centers = _gen.gaussian_clusters(6, 500, 4, seed=5)
+    Y = Y[np.random.default_rng(1).permutation(Y.shape[0])]
+    base = cluster_microstates(Y, n_states=6, random_state=3, max_iter=50, tolerance=1e-6)
+    # accepted and without effect on the device estimator
+    same = cluster_microstates(Y, method="kmeans", n_states=6, random_state=3, max_iter=50, tolerance=1e-6, n_jobs=4,
+                               progress=None, init_strategy="kmeans++", metric="euclidean")
+    np.testing.assert_array_equal(base.labels, same.labels)
+    mb = cluster_microstates(Y, method="minibatchkmeans", n_states=6, random_state=3, max_iter=50, tolerance=1e-6,
+                             batch_size=256)
+    np.testing.assert_array_equal(base.labels, mb.labels)
+    # initial_centers (the reference's spelling) starts the fit there: the true centres recover the blobs
+    seeded = cluster_microstates(Y, n_states=6, initial_centers=true_centers, max_iter=20)
+    assert seeded.n_states == 6
+    for j in range(6):
+        assert np.linalg.norm(seeded.centers[j] - true_centers[j]) < 0.1
+    np.testing.assert_array_equal(seeded.labels, cluster_microstates(Y, n_states=6, init_centers=true_centers,
+                                                                      max_iter=20).labels)
+    # fixed_seed replaces random_state as the seed
+    a = cluster_microstates(Y, n_states=6, random_state=None, fixed_seed=11)
+    b = cluster_microstates(Y, n_states=6, random_state=11)
+    np.testing.assert_array_equal(a.labels, b.labels)
+    assert cluster_microstates(Y, n_states=6, fixed_seed=True).n_states == 6
+    # restarts (n_init) keep the lowest inertia: never worse than the first seed alone
+    r = cluster_microstates(Y, n_states=6, random_state=3, n_init=4)
+    def inertia(res):
+        return float(((Y - res.centers[res.labels]) ** 2).sum())
+    assert inertia(r) <= inertia(cluster_microstates(Y, n_states=6, random_state=3)) * (1 + 1e-12)
+    # the reference's errors
+    with pytest.raises(TypeError, match="batch_size"):
+        cluster_microstates(Y, method="kmeans", n_states=6, batch_size=64)
+    with pytest.raises(ValueError, match="batch_size"):
+        cluster_microstates(Y, method="auto", n_states=6, batch_size=64)        # auto picks kmeans at this size
+    with pytest.raises(ValueError, match="n_init cannot be combined"):
+        cluster_microstates(Y, n_states=6, n_init=3, fixed_seed=5)
+    with pytest.raises(TypeError, match="fixed_seed"):
+        cluster_microstates(Y, n_states=6, fixed_seed="7")
+    with pytest.raises(ValueError, match="positive"):
+        cluster_microstates(Y, n_states=0)
+    with pytest.raises(TypeError, match="Unsupported clustering parameters"):
+        cluster_microstates(Y, n_states=6, n_clusters=6)
+    # fewer occupied states than requested: labels are densified, centres follow
+    dup = np.repeat(np.array([[0.0, 0.0], [5.0, 5.0], [9.0, 0.0]]), 50, axis=0)
+    few = cluster_microstates(dup, n_states=8, random_state=0)
+    assert few.n_states == 3 and sorted(np.unique(few.labels)) == [0, 1, 2] and few.centers.shape == (3, 2)
 
 
 # ---- estimation (test_markov_state_model.py:18-61, test_deeptime_backend.py:95-109) -------

@@ -12,6 +12,7 @@ import pytest
 from scipy import stats
 
 from oracle import npport
+from tests import _gen
 from pmarlo_amd.markov_state_model import compute_implied_timescales
 
 pytestmark = pytest.mark.gpu
@@ -164,3 +165,46 @@ def test_deterministic_its_from_counts(engine):
     np.testing.assert_allclose(rates, 1.0 / ts_ref, rtol=1e-8)
     ev2, ts2, _ = deterministic_its_from_counts(C[:2, :2], 1, 4)          # more timescales than the chain has
     assert np.isfinite(ts2[0]) and np.all(np.isnan(ts2[1:])) and np.all(ev2[1:] == 0.0)
+
+
+def test_deterministic_its_reference_quirk(engine):
+    """reference_quirk=True: what the reference's fall-back RETURNS (uniform "pi" -> eigvalsh on the lower triangle
+    of the non-symmetric T, S/markov_state_model/_its.py:753-787) against its numpy restatement, and how far that is
+    from the intended estimate on a metastable chain."""
+    from pmarlo_amd.markov_state_model import deterministic_its_from_counts
+
+    lab = _gen.metastable_labels(200_000, 60, 4, seed=2)
+    C = np.zeros((60, 60))
+    np.add.at(C, (lab[:-5], lab[5:]), 1.0)
+    ev_q, ts_q, rates_q = deterministic_its_from_counts(C, 5, 4, reference_quirk=True)
+    ev_r, ts_r, rates_r = npport.reference_quirk_its_from_counts(C, 5, 4)
+    np.testing.assert_allclose(ev_q, ev_r, rtol=1e-9)
+    np.testing.assert_allclose(ts_q, ts_r, rtol=1e-8)
+    np.testing.assert_allclose(rates_q, rates_r, rtol=1e-8)
+    ev_i, ts_i, _ = deterministic_its_from_counts(C, 5, 4)
+    # the quirk is not a rounding matter: it moves the slowest timescale of this chain by about 18 %
+    rel = np.abs(ts_q - ts_i) / ts_i
+    assert 0.05 < rel[0] < 0.4 and rel[3] < 1e-2
+    # symmetric counts with equal row sums: T is symmetric, both forms agree
+    S = np.full((6, 6), 2.0) + 10.0 * np.eye(6)
+    a = deterministic_its_from_counts(S, 2, 3, reference_quirk=True)
+    b = deterministic_its_from_counts(S, 2, 3)
+    np.testing.assert_allclose(a[1], b[1], rtol=1e-8)
+    # more timescales than states: padded as the reference pads
+    e2, t2, _ = deterministic_its_from_counts(C[:3, :3], 1, 5, reference_quirk=True)
+    assert np.all(np.isnan(t2[2:])) and np.all(e2[2:] == 0.0)
+
+
+def test_its_input_rules_of_the_reference(engine):
+    """_validate_its_inputs (S/markov_state_model/_its.py:453-524): an empty trajectory in the list empties the result
+    (max_valid_lag = -1), lags above min(len) - 1 are dropped, effective_frames caps the largest lag with a ValueError."""
+    traj = _gen.metastable_labels(4000, 6, 2, seed=1)
+    res = compute_implied_timescales([traj, np.array([], dtype=np.int32)], 6, lag_times=[1, 2], n_timescales=2, n_samples=0)
+    assert res.lag_times.size == 0 and res.timescales.shape == (0, 2)
+    assert compute_implied_timescales([], 6, lag_times=[1], n_timescales=2, n_samples=0).lag_times.size == 0
+    short = compute_implied_timescales([traj, traj[:4]], 6, lag_times=[1, 3, 4, 50], n_timescales=2, n_samples=0)
+    np.testing.assert_array_equal(short.lag_times, [1, 3])
+    with pytest.raises(ValueError, match="effective frames"):
+        compute_implied_timescales([traj], 6, lag_times=[1, 100], n_timescales=2, n_samples=0, effective_frames=100)
+    ok = compute_implied_timescales([traj], 6, lag_times=[1, 99], n_timescales=2, n_samples=0, effective_frames=100)
+    np.testing.assert_array_equal(ok.lag_times, [1, 99])
