@@ -860,12 +860,11 @@ msm_status launch_filter_nm(msm_ctx* ctx, const T* x, int64_t n, int d, int64_t 
     const int n_tiles = ((k16 / 16) + 1) & ~1;
     // staged centre tables: image | fp64 rows | guard flag
     const size_t img_bytes = (size_t)n_tiles * NM * 1024, cs_bytes = (size_t)n_tiles * 16 * S::D1 * sizeof(double);
-    msm_status rs = msm_reserve_aux(ctx, img_bytes + cs_bytes + 16);
+    msm_status rs = msm_reserve_aux(ctx, img_bytes + cs_bytes + (size_t)n_tiles * sizeof(int));
     if (rs != MSM_OK) return rs;
     uint4* img_g = (uint4*)ctx->aux;
     double* cs_g = (double*)((char*)ctx->aux + img_bytes);
-    int* flag = (int*)((char*)ctx->aux + img_bytes + cs_bytes);
-    MSM_HIP(ctx, hipMemsetAsync(flag, 0, sizeof(int), ctx->stream));
+    int* flag = (int*)((char*)ctx->aux + img_bytes + cs_bytes);   // one word per tile, rewritten by every launch
     hipLaunchKernelGGL((kmeans_filter_stage_kernel<NM>), dim3(n_tiles), dim3(64), 0, ctx->stream, centers, k, d, img_g, cs_g,
                        flag);
     MSM_CHECK_LAUNCH(ctx);

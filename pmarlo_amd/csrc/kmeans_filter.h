@@ -91,9 +91,27 @@ __global__ __launch_bounds__(256) void kmeans_pack_kernel(const T* __restrict__ 
     double q = 0.0;
     bool ok = true;
     double v[D];
+    if constexpr (sizeof(T) == 8 && D % 2 == 0) {
+        // fp64 rows of an even width on 16-byte boundaries: D / 2 vector loads (the scalar form cost 4x the bytes
+        // at the memory side: neighbouring lanes share every 128-byte line)
+        if (((ld * sizeof(T)) & 15) == 0 && (((uintptr_t)x) & 15) == 0) {
+            const double2* r2 = reinterpret_cast<const double2*>(row);
+#pragma unroll
+            for (int f2 = 0; f2 < D / 2; ++f2) {
+                const double2 w = r2[f2];
+                v[2 * f2] = w.x;
+                v[2 * f2 + 1] = w.y;
+            }
+        } else {
+#pragma unroll
+            for (int f = 0; f < D; ++f) v[f] = load_as_f64(row + f);
+        }
+    } else {
+#pragma unroll
+        for (int f = 0; f < D; ++f) v[f] = load_as_f64(row + f);
+    }
 #pragma unroll
     for (int f = 0; f < D; ++f) {
-        v[f] = load_as_f64(row + f);
         if (mean) v[f] = (v[f] - mean[f]) / stdv[f];
         const double a = fabs(v[f]);
         ok = ok && (v[f] == 0.0 || (a >= kFilterLo && a <= kFilterHi));   // false for NaN
@@ -126,7 +144,7 @@ __global__ __launch_bounds__(256) void kmeans_pack_kernel(const T* __restrict__ 
 //   img   [n_tiles][NM][64] uint4      A operands, lane-major per instruction
 //   cs64  [n_tiles * 16][DP + 2] f64   centre coordinates zero-padded to DP features, then h_j (+inf for padding
 //                                      rows), then one pad double (rows are 16-byte aligned): refinement and scan
-//   flag  int                          a centre failed the range guard: every frame takes the exhaustive scan
+//   flag  int [n_tiles]                a centre of the tile failed the range guard: every frame takes the exhaustive scan
 // The main kernel copies img + cs64 into its LDS with 16-byte loads.  DP = 4 (NM = 1) or 10 (NM = 2): the fp64
 // chains run over DP features with zeros beyond d, which leaves every partial sum unchanged.
 // ---------------------------------------------------------------------------------------------------------
@@ -151,6 +169,7 @@ __global__ __launch_bounds__(64) void kmeans_filter_stage_kernel(const double* _
         const int m = sl >> 5, qq = (sl & 31) >> 3, e = sl & 7;
         return ((m * 64) + qq * 16 + i) * 8 + e;
     };
+    int bad_row = 0;
     if (lane < 16) {
         const int j = tile * 16 + lane;
         double* row = cs_g + (size_t)j * S::D1;
@@ -166,7 +185,7 @@ __global__ __launch_bounds__(64) void kmeans_filter_stage_kernel(const double* _
                 ok = ok && (c == 0.0 || (ac >= kFilterLo && ac <= kFilterHi));
             }
             h = 0.5 * a;
-            if (!ok) atomicOr(flag, 1);
+            if (!ok) bad_row = 1;
             unsigned hs[3];
             bf16_split3(-(h - kappa * h), hs);
             simg[slot_addr(lane, 6 * d)] = (unsigned short)hs[0];
@@ -192,6 +211,8 @@ __global__ __launch_bounds__(64) void kmeans_filter_stage_kernel(const double* _
     }
     __syncthreads();
     for (int i = lane; i < NM * 64; i += 64) img_g[(size_t)tile * NM * 64 + i] = reinterpret_cast<const uint4*>(simg)[i];
+    const bool any_bad = __any(bad_row != 0);      // one wave per tile: every launch rewrites its flag
+    if (lane == 0) flag[tile] = any_bad ? 1 : 0;
 }
 
 // cross-row butterflies over the 4 lanes (j, j + 16, j + 32, j + 48) that share a frame: v_permlane16_swap /
@@ -275,7 +296,9 @@ __global__ __launch_bounds__(1024, 4) void kmeans_filter_kernel(
         for (int i = tid; i < nv_img; i += kMT) img[i] = img_g[i];
         for (int i = tid; i < nv_cs; i += kMT) cs64v[i] = cs_gv[i];
     }
-    const bool all_scan = *flag_g != 0;
+    int bad_tiles = 0;
+    for (int t = 0; t < n_tiles; ++t) bad_tiles |= flag_g[t];
+    const bool all_scan = bad_tiles != 0;
     __syncthreads();
     KSTAMP(0);
 
