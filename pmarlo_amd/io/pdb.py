@@ -17,12 +17,40 @@ import numpy as np
 __all__ = ["Topology", "Trajectory", "load_pdb"]
 
 
+def _guess_element(atom_name: str) -> str:
+    """Element symbol from a PDB atom name when columns 77-78 are blank: leading digits dropped, two-letter symbols
+    only for the common ions / halogens."""
+    nm = atom_name.strip().lstrip("0123456789")
+    if not nm:
+        return ""
+    two = nm[:2].upper()
+    if two in ("CL", "BR", "NA", "MG", "ZN", "FE", "MN", "CU", "LI") and len(nm) == 2:
+        return two[0] + two[1].lower()
+    return nm[0].upper()
+
+
 @dataclass
 class Topology:
     atom_names: list[str]
     res_names: list[str]
     res_index: np.ndarray          # per-atom 0-based residue index (in file order)
     chain_ids: list[str] = field(default_factory=list)
+    res_seq: np.ndarray | None = None      # per-atom PDB residue number (mdtraj resSeq); default res_index + 1
+    elements: list[str] | None = None      # per-atom element symbol; default: derived from the atom name
+    serials: np.ndarray | None = None      # per-atom PDB serial; default index + 1
+
+    def __post_init__(self):
+        n = len(self.atom_names)
+        self.res_index = np.asarray(self.res_index, dtype=int)
+        if self.res_seq is None:
+            self.res_seq = self.res_index + 1
+        if self.serials is None:
+            self.serials = np.arange(1, n + 1)
+        if self.elements is None:
+            self.elements = [_guess_element(nm) for nm in self.atom_names]
+        # 0-based chain index in order of first appearance (mdtraj chainid)
+        seen: dict[str, int] = {}
+        self.chain_index = np.asarray([seen.setdefault(c, len(seen)) for c in (self.chain_ids or [""] * n)], dtype=int)
 
     @property
     def n_atoms(self) -> int:
@@ -33,14 +61,11 @@ class Topology:
         return int(self.res_index.max()) + 1 if len(self.res_index) else 0
 
     def select(self, query: str) -> np.ndarray:
-        """Supports the selections the path uses: ``name X`` and ``all``."""
-        q = query.strip()
-        if q == "all":
-            return np.arange(self.n_atoms)
-        parts = q.split()
-        if len(parts) == 2 and parts[0] == "name":
-            return np.asarray([i for i, nm in enumerate(self.atom_names) if nm == parts[1]], dtype=int)
-        raise ValueError(f"unsupported selection {query!r} (supported: 'all', 'name <atom>')")
+        """mdtraj-style selection strings (pmarlo_amd/io/selection.py: name / resname / resid / resSeq / index /
+        chainid / element, ranges, comparisons, protein / backbone / sidechain / water, and / or / not)."""
+        from .selection import select as _select
+
+        return _select(self, query)
 
     def _atom(self, res: int, name: str) -> int | None:
         for i in np.nonzero(self.res_index == res)[0]:
@@ -129,6 +154,9 @@ def load_pdb(path: str | Path) -> Trajectory:
     resn: list[str] = []
     chains: list[str] = []
     res_keys: list[tuple] = []
+    serials: list[int] = []
+    resseq: list[int] = []
+    elems: list[str] = []
     first = True
     with open(path) as fh:
         for line in fh:
@@ -140,6 +168,16 @@ def load_pdb(path: str | Path) -> Trajectory:
                     resn.append(line[17:20].strip())
                     chains.append(line[21:22])
                     res_keys.append((line[21:22], line[22:27]))
+                    try:
+                        serials.append(int(line[6:11]))
+                    except ValueError:
+                        serials.append(len(serials) + 1)
+                    try:
+                        resseq.append(int(line[22:26]))
+                    except ValueError:
+                        resseq.append(0)
+                    el = line[76:78].strip() if len(line) >= 78 else ""
+                    elems.append(el.capitalize() if el else _guess_element(line[12:16]))
             elif rec == "ENDMDL":
                 if cur:
                     models.append(cur)
@@ -160,4 +198,5 @@ def load_pdb(path: str | Path) -> Trajectory:
             last = key
         res_index[i] = idx
     xyz = np.asarray(models, dtype=np.float64) / 10.0
-    return Trajectory(xyz.astype(np.float32), Topology(names, resn, res_index, chains))
+    return Trajectory(xyz.astype(np.float32), Topology(names, resn, res_index, chains, np.asarray(resseq), elems,
+                                                      np.asarray(serials)))

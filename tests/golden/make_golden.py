@@ -630,7 +630,78 @@ def golden_whitening():
     np.savez_compressed(OUT / "whitening.npz", **out)
 
 
+# ---- 20. the reference's own trajectory fixtures (tests/_assets): a truncated copy + struct-level facts --------
+def golden_real_assets():
+    """tests/_assets/traj.dcd (100 frames x 3 350 atoms, unit cells, written by OpenMM) and 3gd8-fixed.pdb are the
+    files the reference's own tests load through mdtraj (tests/conftest.py:208-229).  Stored: the header and the first
+    four frames of the DCD byte for byte (frame count patched to 4), the PDB text, and what an independent parse with
+    `struct` / column slicing says about them (header fields, unit cells, coordinates, atom / residue tables)."""
+    import struct
+
+    assets = REF / "tests" / "_assets"
+    raw = (assets / "traj.dcd").read_bytes()
+    nf_keep = 4
+    blk = struct.unpack_from("<i", raw, 0)[0]
+    assert blk == 84 and raw[4:8] == b"CORD"
+    icntrl = struct.unpack_from("<9i", raw, 8)
+    delta = struct.unpack_from("<f", raw, 8 + 36)[0]
+    tail = struct.unpack_from("<10i", raw, 8 + 40)
+    off = 4 + 84 + 4
+    tsize = struct.unpack_from("<i", raw, off)[0]
+    ntitle = struct.unpack_from("<i", raw, off + 4)[0]
+    title = raw[off + 8:off + 8 + 80].split(b"\x00")[0].decode()
+    off += 4 + tsize + 4
+    assert struct.unpack_from("<i", raw, off)[0] == 4
+    natoms = struct.unpack_from("<i", raw, off + 4)[0]
+    off += 12
+    has_cell = tail[0] == 1
+    frame_bytes = (56 if has_cell else 0) + 3 * (4 * natoms + 8)
+    assert len(raw) == off + icntrl[0] * frame_bytes
+    cells, xyz = [], []
+    for fr in range(nf_keep):
+        o = off + fr * frame_bytes
+        if has_cell:
+            assert struct.unpack_from("<i", raw, o)[0] == 48
+            cells.append(struct.unpack_from("<6d", raw, o + 4))
+            o += 56
+        cols = []
+        for ax in range(3):
+            assert struct.unpack_from("<i", raw, o)[0] == 4 * natoms
+            cols.append(np.frombuffer(raw, dtype="<f4", count=natoms, offset=o + 4).copy())
+            o += 4 * natoms + 8
+        xyz.append(np.stack(cols, axis=1))
+    xyz = np.asarray(xyz)                       # Angstrom, as stored
+    keep = bytearray(raw[:off + nf_keep * frame_bytes])
+    struct.pack_into("<i", keep, 8, nf_keep)    # NSET of the truncated copy
+    pdb_text = (assets / "3gd8-fixed.pdb").read_bytes()
+    names, resn, resseq, elems, chains = [], [], [], [], []
+    for line in pdb_text.decode().splitlines():
+        if line.startswith(("ATOM  ", "HETATM")):
+            names.append(line[12:16].strip())
+            resn.append(line[17:20].strip())
+            chains.append(line[21])
+            resseq.append(int(line[22:26]))
+            elems.append(line[76:78].strip())
+    res_change = np.r_[True, [(chains[i], resseq[i]) != (chains[i - 1], resseq[i - 1]) for i in range(1, len(names))]]
+    res_index = np.cumsum(res_change) - 1
+    np.savez_compressed(
+        OUT / "real_assets.npz",
+        dcd_bytes=np.frombuffer(bytes(keep), np.uint8), pdb_text=np.frombuffer(pdb_text, np.uint8),
+        dcd_n_frames_total=np.int64(icntrl[0]), dcd_istart=np.int64(icntrl[1]), dcd_nsavc=np.int64(icntrl[2]),
+        dcd_delta=np.float32(delta), dcd_has_cell=np.int64(has_cell), dcd_charmm_version=np.int64(tail[9]),
+        dcd_natoms=np.int64(natoms), dcd_ntitle=np.int64(ntitle), dcd_title=np.frombuffer(title.encode(), np.uint8),
+        dcd_cells_raw=np.asarray(cells), dcd_xyz_angstrom_head=xyz[:, :8], dcd_xyz_angstrom_tail=xyz[:, -8:],
+        dcd_xyz_sums=xyz.astype(np.float64).sum(axis=1), dcd_xyz_sq_sums=(xyz.astype(np.float64) ** 2).sum(axis=1),
+        pdb_natoms=np.int64(len(names)), pdb_nres=np.int64(res_index[-1] + 1),
+        pdb_ca=np.flatnonzero(np.asarray(names) == "CA"), pdb_n_hydrogen=np.int64(sum(e == "H" for e in elems)),
+        pdb_first_names=np.frombuffer(" ".join(names[:12]).encode(), np.uint8),
+        pdb_first_resnames=np.frombuffer(" ".join(np.asarray(resn)[np.flatnonzero(res_change)[:8]]).encode(), np.uint8),
+        pdb_resseq_first_last=np.asarray([resseq[0], resseq[-1]]), pdb_res_index_sha=np.frombuffer(
+            bytes.fromhex(sha(res_index.astype(np.int64))), np.uint8))
+
+
 if __name__ == "__main__":
+    golden_real_assets()
     golden_whitening()
     golden_fes_smoothing()
     golden_msm_fes()
