@@ -46,6 +46,14 @@ class MSMDiscretizationResult:
     pruned_state_indices: np.ndarray | None = None
 
 
+def _device_ready(X: np.ndarray) -> np.ndarray:
+    """C-contiguous float32 / float64 as given (no re-typing pass over N x d on the host); anything else -> float64."""
+    X = np.asarray(X)
+    if X.dtype not in (np.float32, np.float64):
+        X = X.astype(np.float64)
+    return np.ascontiguousarray(X)
+
+
 class NoAssignmentsError(ValueError):
     """Defined by the reference but never raised there (it raises ValueError, :797)."""
 
@@ -247,7 +255,7 @@ class KMeansDiscretizer:
         schema["names"] = [str(v) for v in names] if names else [f"feature_{i}" for i in range(d)]
         schema["n_features"] = d
         self.feature_schema = schema
-        xd = eng.to_device(np.ascontiguousarray(X, np.float64))
+        xd = eng.to_device(_device_ready(X))      # float32 / float64 go up as they are: the kernels read both
         whiten = None
         if self.apply_whitening:
             mean, std, _ = eng.column_moments(xd, ddof=1)
@@ -273,8 +281,7 @@ class KMeansDiscretizer:
         if feature_schema is not None and self.feature_schema is not None:
             _validate_feature_schema(self.feature_schema, feature_schema, split_name=split_name or "split")
         eng = self._eng
-        labels = eng.kmeans_assign(eng.to_device(np.ascontiguousarray(X, np.float64)), self._centers_d,
-                                   mean=self._mean_d, std=self._std_d)
+        labels = eng.kmeans_assign(eng.to_device(_device_ready(X)), self._centers_d, mean=self._mean_d, std=self._std_d)
         return labels.to_host().astype(np.int32, copy=False)
 
     @property

@@ -87,7 +87,8 @@ struct TileSplit {
 template <typename T, int NT, bool VEC, int HALF, bool FINITE>
 __device__ __forceinline__ void cov_wave_body(const T* __restrict__ x, int F, int64_t ld, const FrameTab& ft,
                                               const double* __restrict__ mu, int64_t frames_per_wave,
-                                              int frame_wave, int n_frame_waves, double* red, int red_wave) {
+                                              int frame_wave, int n_frame_waves, double* red, int red_wave,
+                                              volatile int* prog = nullptr) {
     using S = CovShape<NT>;
     using TS = TileSplit<NT>;
     const int lane = threadIdx.x & 63;
@@ -141,6 +142,20 @@ __device__ __forceinline__ void cov_wave_body(const T* __restrict__ x, int F, in
         }
     };
 
+    // The two waves that share a frame run (HALF 0 / 1: the same frames, different tiles) read the same rows of X.
+    // Left alone they drift apart by more than the CU's share of the L2 holds, and every row is then fetched from
+    // memory twice (2.0x the algorithmic bytes in the round-1 FETCH_SIZE profile).  A rendezvous every 8 frame groups
+    // through two LDS words keeps them within 16 groups (16 KB) of each other: the second reader hits L1 / L2.
+    int my_groups = 0;
+    auto rendezvous = [&]() {
+        if constexpr (HALF >= 0) {
+            if ((my_groups & 7) == 0) {
+                if (lane == 0) prog[2 * red_wave + HALF] = my_groups;
+                while (prog[2 * red_wave + (1 - HALF)] + 8 < my_groups) __builtin_amdgcn_s_sleep(1);
+            }
+            ++my_groups;
+        }
+    };
     int seg = 0;  // wave-uniform
     int64_t q0 = q_begin;
     while (q0 < q_end) {
@@ -152,6 +167,7 @@ __device__ __forceinline__ void cov_wave_body(const T* __restrict__ x, int F, in
         double wx, wy;
         load_group(t, s_start, s_stop, rx, ry, wx, wy);
         for (; q0 < q_hi; q0 += 4) {
+            rendezvous();
             // consume the prefetched group into fp64 operands
             double za[NT], zb[NT], zy[NT];
             const double w = fma(ft.wy_w, wy, wx);
@@ -193,6 +209,9 @@ __device__ __forceinline__ void cov_wave_body(const T* __restrict__ x, int F, in
         }
     }
 
+    if constexpr (HALF >= 0) {
+        if (lane == 0) prog[2 * red_wave + HALF] = 0x7ffffff0;   // done: never hold the partner back
+    }
     // ---- workgroup reduction: waves of a half add their tiles in wave order ----
     double* sums = red + S::kTiles * 256;  // [4][2][NT][64]
 #pragma unroll
@@ -238,8 +257,11 @@ __global__ __launch_bounds__(SPLIT ? 512 : 256, SPLIT ? 2 : 1) void cov_fused_ke
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     if constexpr (SPLIT) {
-        if (wave < 4) cov_wave_body<T, NT, VEC, 0, FINITE>(x, F, ld, ft, mu, frames_per_wave, wave, 4, red, wave);
-        else cov_wave_body<T, NT, VEC, 1, FINITE>(x, F, ld, ft, mu, frames_per_wave, wave - 4, 4, red, wave - 4);
+        __shared__ int prog[8];   // progress of the 4 wave pairs (frame groups done), see cov_wave_body
+        if (tid < 8) prog[tid] = 0;
+        __syncthreads();
+        if (wave < 4) cov_wave_body<T, NT, VEC, 0, FINITE>(x, F, ld, ft, mu, frames_per_wave, wave, 4, red, wave, prog);
+        else cov_wave_body<T, NT, VEC, 1, FINITE>(x, F, ld, ft, mu, frames_per_wave, wave - 4, 4, red, wave - 4, prog);
     } else {
         cov_wave_body<T, NT, VEC, -1, FINITE>(x, F, ld, ft, mu, frames_per_wave, wave, 4, red, wave);
     }

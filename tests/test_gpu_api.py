@@ -466,3 +466,21 @@ def test_validate_features_vs_reference_golden(engine, golden):
                 assert stats[key] == val, (name, key)
     with pytest.raises(ValueError):
         validate_features(np.zeros(5), None)
+
+
+def test_device_view_keeps_its_allocation_alive(engine):
+    """Regression test for a use-after-free (commit d301652): a view of a device array outlived the base array it
+    pointed into (the stationary vector inside compute_committor), so the allocator could hand the memory to the next
+    call.  A view now holds a reference to its base: dropping the base must not free the memory under the view."""
+    import gc
+
+    base = engine.to_device(np.arange(1024, dtype=np.float64))
+    view = base.view((16,), offset_elems=512)
+    chained = view.view((4,), offset_elems=8)
+    del base
+    gc.collect()
+    # churn the allocator: same-sized allocations would reuse a freed block at once
+    junk = [engine.to_device(np.full(1024, -1.0)) for _ in range(32)]
+    np.testing.assert_array_equal(view.to_host(), np.arange(512, 528, dtype=np.float64))
+    np.testing.assert_array_equal(chained.to_host(), np.arange(520, 524, dtype=np.float64))
+    del junk

@@ -86,6 +86,28 @@ def test_fit_inertia_vs_reference_sklearn(engine, n, d, k):
     assert inertia <= ref_inertia * 1.05, (inertia, ref_inertia)
 
 
+def test_fit_inertia_vs_the_reference_estimator_at_c2(engine):
+    """BASELINE config 2 (100 K x 4, k = 100) against the estimator the reference really runs at this size:
+    sklearn KMeans(n_clusters, random_state, n_init=10) on the whitened data (S/analysis/discretize.py:458-469).
+    The engine gets the same number of restarts through cluster_microstates-style seeding (10 seeded starts, lowest
+    inertia) and full-batch Lloyd to sklearn's tolerance; its inertia must be within 2 % of the reference's."""
+    from sklearn.cluster import KMeans
+
+    n, d, k = 100_000, 4, 100
+    X = _gen.correlated_series(n, d, seed=1000).astype(np.float64)
+    mean, std = X.mean(axis=0), X.std(axis=0, ddof=1)
+    Xz = (X - mean) / std
+    ref = KMeans(n_clusters=k, random_state=0, n_init=10).fit(Xz)
+    best = np.inf
+    md = engine.empty((n,), np.float64)
+    md_, sd_ = engine.to_device(mean), engine.to_device(std)
+    for r in range(10):
+        centers, st, xd = _fit(engine, X, k, seed=r, max_iter=300, tol2=1e-4, mean=mean, std=std)
+        engine.kmeans_assign(xd, engine.to_device(centers), mean=md_, std=sd_, mindist=md)
+        best = min(best, float(engine.sum_f64(md).to_host()[0]))
+    assert best <= float(ref.inertia_) * 1.02, (best, float(ref.inertia_))
+
+
 def test_accumulate_update_split_equals_fit(engine):
     """The shard-wise API (accumulate on two halves, summed int64, one update) equals the
     single-device fit bit for bit: what makes the multi-GPU fit shard-count independent."""
