@@ -812,7 +812,7 @@ bool filter_enabled() {
 int filter_stagger() {
     static const int v = [] {
         const char* e = getenv("MSM_KMEANS_STAGGER");   // start offset between the waves of a SIMD, units of 512 cycles
-        return e ? atoi(e) : 4;
+        return e ? atoi(e) : 0;   // measured: no effect (tools/run/kmf.sh sweep), kept as a diagnostic knob
     }();
     return v;
 }
