@@ -511,34 +511,53 @@ __device__ void lower_inverse(const double* G, double* X, int n, int ld) {
 
 // ---------------------------------------------------------------------------------------------------
 // Symmetric eigensolver for n <= 64 without the ~600 barrier-bound Jacobi rounds:
-//   (1) Householder tridiagonalisation A = Q T Q' with Q accumulated (n - 2 steps, 3 barriers each:
-//       reflector by wave 0, the two matrix-vector products A v and Q v with 8 lanes per row, rank-2 / rank-1
-//       updates by everybody);
-//   (2) all eigenvalues of T at once by multisection on Sturm counts: 4 lanes per eigenvalue, 4 trial points
-//       per round, 27 rounds; the count uses the product recurrence
-//       p_j = (d_j - x) p_{j-1} - e_{j-1}^2 p_{j-2} (one dependent fma per row, no division), rescaled every 8 rows;
+//   (1) Householder tridiagonalisation A = Q T Q' with A and Q' held in the registers of eight waves (householder_phase
+//       below: rows dealt out four ways, lane = column, two barriers per column);
+//   (2) all eigenvalues of T at once by multisection on Sturm counts: 8 lanes per eigenvalue (two waves per SIMD: a
+//       lone wave only gets every other issue slot), 8 trial points per round, 20 rounds; the count uses the product
+//       recurrence p_j = (d_j - x) p_{j-1} - e_{j-1}^2 p_{j-2} (no division), sign changes shifted into a bit mask,
+//       rescaled every 8 rows;
 //   (3) one eigenvector of T per lane from the twisted factorisation of T - lambda I (forward and backward
 //       pivots, twist at the smallest |gamma|: Parlett & Dhillon), i.e. one exact inverse-iteration step;
-//   (4) Z = Q X.
+//   (4) Z = Q X on the matrix cores, the 1/|x| factors folded into the operand.
 // Eigenvectors of T belonging to eigenvalues closer than ~1e-9 |T| come out of (3) short of orthogonal, and
 // exactly repeated eigenvalues give repeated vectors: X'X is checked and the caller falls back to Jacobi on its
 // copy of A when the defect exceeds `orth_tol` (or a residual |T x - lambda x| is large).
 // ---------------------------------------------------------------------------------------------------
 #ifdef MSM_TRI_STAMPS
-__device__ unsigned long long g_tri_stamps[8];
+__device__ unsigned long long g_tri_stamps[24];
 #define TSTAMP(i) do { if (threadIdx.x == 0) { unsigned long long t__; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t__)::"memory"); g_tri_stamps[i] += t__ - tlast__; tlast__ = t__; } } while (0)
 #define TSTAMP_INIT unsigned long long tlast__ = 0; if (threadIdx.x == 0) { asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tlast__)::"memory"); }
+#define KSTAMP(i) do { if (threadIdx.x == 0) { unsigned long long t__; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t__)::"memory"); g_tri_stamps[i] += t__ - klast__; klast__ = t__; } } while (0)
+#define KSTAMP_INIT unsigned long long klast__ = 0; if (threadIdx.x == 0) { asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(klast__)::"memory"); }
+#ifdef MSM_TRI_STAMPS_FINE
+#define LSTAMP(i) TSTAMP(i)
+#define LSTAMP_INIT TSTAMP_INIT
 #else
+#define LSTAMP(i)
+#define LSTAMP_INIT
+#endif
+#else
+#define LSTAMP(i)
+#define LSTAMP_INIT
 #define TSTAMP(i)
 #define TSTAMP_INIT
+#define KSTAMP(i)
+#define KSTAMP_INIT
 #endif
 constexpr int kTriMax = 64;
+constexpr int kTriLd = 65;   // row stride of every matrix handed to tridiag_eigh (a constant: row offsets become immediates)
 struct TriShared {
-    double d[kTriMax], e[kTriMax], e2[kTriMax], lam[kTriMax], vv[kTriMax], praw[kTriMax], uq[kTriMax];
-    double tau, scale, gl, gu;
+    double2 de[kTriMax + 8];   // {d_j, e_{j-1}^2} of the scaled matrix; rows n.. are {8, 0} (no sign change)
+    double d[kTriMax], e[kTriMax], lam[kTriMax], praw[kTriMax], uq[kTriMax], inv[kTriMax];
+    double scale, gl, gu;
     double red[kEigThreads / 64];
     int bad;
+    double part[8][kTriMax];   // partial products of the tridiagonalisation, one row per working wave
+    double2 vw[8][kTriMax];    // {v_j, w_j} of the column in flight, one copy per working wave
 };
+
+typedef double tri_v4f64 __attribute__((ext_vector_type(4)));
 
 // 64-lane sum on the VALU (row DPP moves, then the two row swaps of gfx950): every lane gets the total, bit for
 // bit the same in every wave that feeds it the same numbers
@@ -574,122 +593,306 @@ __device__ __forceinline__ double wave_sum_all(double x) {
     return x;
 }
 
-// # eigenvalues of the (scaled) tridiagonal matrix below x.  Rows are taken eight at a time: their d and e^2
-// come out of the LDS in one burst, the recurrence itself is one dependent fma per row.
-__device__ __forceinline__ int sturm_count(const TriShared* ts, int n, double x) {
-    // sign changes of p_0 = 1, p_1, ..., p_n, read off the sign bits (an exact zero counts as positive: it only
-    // occurs when x is an eigenvalue of a leading block, and a bracket spoilt by it fails the residual check)
-    double pp = 1.0, p = ts->d[0] - x;
-    unsigned cnt = (unsigned)(__double_as_longlong(p) >> 63) & 1u;
-    auto row = [&](double dj, double e2j) {
-        const double pn = fma(dj - x, p, -(e2j * pp));
-        cnt += (unsigned)((__double_as_longlong(pn) ^ __double_as_longlong(p)) >> 63) & 1u;
-        pp = p;
-        p = pn;
-    };
-    int j = 1;
-    for (; j + 8 <= n; j += 8) {
-        double dd[8], ee[8];
+// C[i][j] = sum_k opA(i,k) opB(k,j) on the matrix cores (v_mfma_f64_16x16x4_f64; one 16 x 16 tile of C per wave
+// and trip), i < rows, j < cols, k < inner; opA = A or A', opB = B or B'.  bscale (optional) multiplies column j of
+// opB.  C must not alias A or B.  A 64^3 product costs what it costs on the VALU (the fp64 rates are equal) but
+// reads each operand from the LDS once per tile instead of once per multiply.
+template <bool TA, bool TB>
+__device__ __forceinline__ void mfma_mm(double* C, const double* A, const double* B, int rows, int cols, int inner, int ld,
+                        const double* bscale = nullptr) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    const int j = lane & 15, g = lane >> 4;
+    const int tr = (rows + 15) >> 4, tc = (cols + 15) >> 4;
+    for (int t = wave; t < tr * tc; t += nw) {
+        const int i0 = (t / tc) * 16, c0 = (t - (t / tc) * tc) * 16;
+        const bool aok = i0 + j < rows, bok = c0 + j < cols;
+        const int ai = aok ? i0 + j : 0, bj = bok ? c0 + j : 0;
+        const double bs = bscale ? bscale[bj] : 1.0;
+        tri_v4f64 acc = {0.0, 0.0, 0.0, 0.0};
+        for (int k0 = 0; k0 < inner; k0 += 16) {   // four instructions per trip: their operand reads go out together
+            double a[4], b[4];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) { dd[u] = ts->d[j + u]; ee[u] = ts->e2[j + u - 1]; }
+            for (int u = 0; u < 4; ++u) {
+                const bool kok = k0 + 4 * u + g < inner;
+                const int k = kok ? k0 + 4 * u + g : 0;
+                a[u] = TA ? A[k * ld + ai] : A[ai * ld + k];
+                b[u] = (TB ? B[bj * ld + k] : B[k * ld + bj]) * bs;
+                if (!(aok && kok)) a[u] = 0.0;
+                if (!(bok && kok)) b[u] = 0.0;
+            }
 #pragma unroll
-        for (int u = 0; u < 8; ++u) row(dd[u], ee[u]);
-        // keep the pair in range (the matrix is scaled to |T| <= 1, so eight rows cannot leave it)
-        const double m = fmax(fabs(p), fabs(pp));
-        if (m > 0.0) {
-            int ex;
-            (void)frexp(m, &ex);
-            p = ldexp(p, -ex);
-            pp = ldexp(pp, -ex);
+            for (int u = 0; u < 4; ++u) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[u], b[u], acc, 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = i0 + g + 4 * r, col = c0 + j;
+            if (row < rows && col < cols) C[row * ld + col] = acc[r];
         }
     }
-    for (; j < n; ++j) row(ts->d[j], ts->e2[j - 1]);
-    return (int)cnt;
+    __syncthreads();
+}
+
+// # eigenvalues of the (scaled) tridiagonal matrix below x: sign changes of p_{-1} = 1, p_0, ..., p_{n-1}, read off
+// the sign bits (an exact zero counts as positive: it only occurs when x is an eigenvalue of a leading block, and a
+// bracket spoilt by it fails the residual check).  Eight rows at a time: their {d, e^2} pairs come out of the LDS in
+// one burst; per row 5 vector instructions (sub, mul, fma, xor, alignbit).
+__device__ __forceinline__ int sturm_count(const TriShared* ts, int nblocks, double x) {
+    double pp = 0.0, p = 1.0;
+    unsigned bits = 0, cnt = 0;
+    for (int b = 0; b < nblocks; ++b) {
+        double2 r[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) r[u] = ts->de[8 * b + u];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const double pn = fma(r[u].x - x, p, -(r[u].y * pp));
+            bits = __builtin_amdgcn_alignbit(bits, (unsigned)(__double2hiint(pn) ^ __double2hiint(p)), 31);
+            pp = p;
+            p = pn;
+        }
+        // keep the pair in range (the matrix is scaled to |T| <= 1, so eight rows cannot leave it)
+        const int ex = max(__builtin_amdgcn_frexp_exp(p), __builtin_amdgcn_frexp_exp(pp));
+        p = ldexp(p, -ex);
+        pp = ldexp(pp, -ex);
+        if ((b & 3) == 3) { cnt += __popc(bits); bits = 0; }
+    }
+    return (int)(cnt + __popc(bits));
+}
+
+// Tridiagonalisation A = Q T Q' with the matrices held in REGISTERS, every wave of the workgroup in lockstep, two
+// barriers per column.
+// Measured on this chip (tools/probe/lone_wave_lds_probe.hip, tri_probe.hip): a wave alone on its CU runs at about one
+// instruction per 10 cycles whatever the instruction (instruction fetch has nobody to hide behind), pays ~37 cycles
+// per taken branch and 12-19 per LDS instruction, so one barrier-free wave sweeping an LDS-resident matrix needed
+// ~5000 cycles per column; sixteen waves sweeping it between barriers were no faster.  Here nothing is swept:
+//   waves 0-3 hold the rows j = w (mod 4) of A for the whole reduction, waves 4-7 the same rows of Q'
+//   (QT[j][r] = Q[r][j]): 16 doubles per lane, indexed by compile-time constants only (lane = column); waves 8.. only
+//   keep the barriers company;
+//   (1) every working wave reads row k (written to the LDS by its owner one column earlier) and forms the reflector
+//       itself (same inputs, same instructions, same bits): x = A[k][k+1:], H = I - tau v v', v_{k+1} = 1;
+//   (2) partial products over the own rows: p = A22 v (A side), u = Q v (Q side); the v_j come back as broadcast reads
+//       of the wave's own LDS copy of v; one LDS row of partials per wave; barrier;
+//   (3) the four partials are summed in a fixed order by everybody who needs them; A side: w = tau p - (tau^2 p.v / 2) v
+//       and a_j -= v_j w + w_j v on the own rows, the owner of row k + 1 leaving it in the LDS; Q side: q_j -= tau v_j u;
+//       barrier.
+// Rows up to k carry v_j = w_j = 0; groups of four own rows that lie entirely there are skipped.
+__device__ __forceinline__ double bcast_lane(double x, int j) {   // lane j's value to everybody; j uniform
+    const long long b = __double_as_longlong(x);
+    const int lo = __builtin_amdgcn_readlane((int)b, j), hi = __builtin_amdgcn_readlane((int)(b >> 32), j);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned)lo);
+}
+template <typename F>
+__device__ __forceinline__ void hh_for_groups(int sub, int k, F&& body) {
+    // own rows sub + 4 t, t = 4 g + u; group g is dead once its last row sub + 16 g + 12 <= k
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+        if (sub + 16 * g + 12 > k) body(g);
+}
+__device__ __forceinline__ void householder_phase(double* A, double* QT, int n, TriShared* ts) {
+    constexpr int ld = kTriLd;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const bool in = lane < n;
+    const int role = wave < 4 ? 0 : (wave < 8 ? 1 : 2);
+    const int sub = wave & 3;
+    double* part = ts->part[(role == 1 ? 4 : 0) + sub];
+    const double* parts = ts->part[role == 1 ? 4 : 0];
+    double2* vw = ts->vw[wave & 7];   // this wave's own copy of {v_j, w_j}
+    double m[16];                     // rows sub + 4 t of A (role 0) or Q' (role 1), column `lane`
+    if (role < 2) {
+#pragma unroll
+        for (int t = 0; t < 16; ++t) {
+            const int j = sub + 4 * t;
+            m[t] = (in && j < n) ? (role == 0 ? A[j * ld + lane] : (j == lane ? 1.0 : 0.0)) : 0.0;
+        }
+    }
+    LSTAMP_INIT
+    for (int k = 0; k + 2 < n; ++k) {
+        LSTAMP(16);
+        double vi = 0.0, tau = 0.0;
+        const bool act = in && lane > k;
+        if (role < 2) {
+            const double* rowk = A + k * ld;
+            double xi = rowk[in ? lane : 0];
+            const double alpha = rowk[k + 1];
+            if (wave == 0 && lane == k) ts->d[k] = xi;
+            if (!act) xi = 0.0;
+            const double sigma = wave_sum_all(lane > k + 1 ? xi * xi : 0.0);
+            double beta = alpha, scal = 0.0;
+            if (__builtin_amdgcn_readfirstlane(sigma != 0.0)) {   // every lane holds the same sigma
+                const double h2 = fma(alpha, alpha, sigma);
+                const double rs = nr_rsqrt(h2);
+                beta = -copysign(h2 * rs, alpha);
+                tau = (beta - alpha) * -copysign(rs, alpha);   // (beta - alpha) / beta
+                scal = nr_rcp(alpha - beta);
+            }
+            vi = act ? (lane == k + 1 ? 1.0 : xi * scal) : 0.0;
+            if (wave == 0 && lane == 0) ts->e[k] = beta;
+            LSTAMP(17);
+            if (__builtin_amdgcn_readfirstlane(tau != 0.0)) {
+                vw[lane].x = vi;
+                double s0 = 0.0, s1 = 0.0;
+                hh_for_groups(sub, k, [&](int g) {
+                    double v[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) v[u] = vw[sub + 16 * g + 4 * u].x;
+                    s0 = fma(m[4 * g], v[0], s0);
+                    s1 = fma(m[4 * g + 1], v[1], s1);
+                    s0 = fma(m[4 * g + 2], v[2], s0);
+                    s1 = fma(m[4 * g + 3], v[3], s1);
+                });
+                part[lane] = s0 + s1;
+            }
+            LSTAMP(18);
+        }
+        __syncthreads();
+        LSTAMP(19);
+        if (role < 2 && __builtin_amdgcn_readfirstlane(tau != 0.0)) {
+            const double p = ((parts[lane] + parts[kTriMax + lane]) + parts[2 * kTriMax + lane]) + parts[3 * kTriMax + lane];
+            if (role == 0) {
+                const double pv = wave_sum_all(act ? p * vi : 0.0);
+                const double al = -0.5 * tau * (tau * pv);
+                const double wi = act ? fma(tau, p, al * vi) : 0.0;
+                vw[lane].y = wi;
+                LSTAMP(20);
+                hh_for_groups(sub, k, [&](int g) {
+                    double2 b[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) b[u] = vw[sub + 16 * g + 4 * u];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        m[4 * g + u] = fma(-wi, b[u].x, fma(-vi, b[u].y, m[4 * g + u]));
+                        if (in && sub + 16 * g + 4 * u == k + 1) A[(k + 1) * ld + lane] = m[4 * g + u];   // next column's x
+                    }
+                });
+            } else {
+                const double tu = -tau * p;
+                hh_for_groups(sub, k, [&](int g) {
+                    double v[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) v[u] = vw[sub + 16 * g + 4 * u].x;
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) m[4 * g + u] = fma(tu, v[u], m[4 * g + u]);
+                });
+            }
+        }
+        LSTAMP(21);
+        __syncthreads();
+    }
+    // back to the LDS: Q' whole, of A the last two rows (the 2 x 2 block the reduction leaves)
+    if (role == 1 && in) {
+#pragma unroll
+        for (int t = 0; t < 16; ++t)
+            if (sub + 4 * t < n) QT[(sub + 4 * t) * ld + lane] = m[t];
+    }
+    if (role == 0 && in) {
+#pragma unroll
+        for (int t = 0; t < 16; ++t)
+            if (sub + 4 * t >= n - 2 && sub + 4 * t < n) A[(sub + 4 * t) * ld + lane] = m[t];
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        ts->d[n - 2] = A[(n - 2) * ld + n - 2];
+        ts->e[n - 2] = A[(n - 1) * ld + n - 2];
+        ts->d[n - 1] = A[(n - 1) * ld + n - 1];
+        ts->e[n - 1] = 0.0;
+    }
+}
+
+// Whitening of a full-rank C00 in registers, the pattern of householder_phase: two LDL' eliminations side by side, one
+// barrier per column.  Waves 0-7 hold the rows i = w (mod 8) of C00 and of X (= identity at the start), waves 8-15 the
+// same rows of the probe C00 - epsilon I; lane = column.  Column j: the owner of row j has left it in the LDS; every
+// wave takes the pivot d_j from it, forms l_i = M[i][j] / d_j for its own rows (the entry sits in lane j: v_readlane) and
+// subtracts l_i x row j from row i of M and of X; the owner of row j + 1 leaves that row in the LDS for the next column.
+// On success W = (D^-1/2 L^-1)' (upper triangular, W' C00 W = I) is written to `W`; false (uniformly) as soon as a pivot
+// of either matrix is not positive.  C is left as it was.  blockDim.x == 1024.
+__device__ __forceinline__ bool ldl_whiten_registers(const double* C, double* W, int n, double epsilon, TriShared* ts) {
+    constexpr int ld = kTriLd;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const bool in = lane < n;
+    const bool probe = wave >= 8;
+    const int sub = wave & 7;
+    double m[8], x[8];
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+        const int i = sub + 8 * t;
+        m[t] = (in && i < n) ? C[i * ld + lane] - (probe && lane == i ? epsilon : 0.0) : 0.0;
+        x[t] = lane == i ? 1.0 : 0.0;
+    }
+    if (sub == 0) {   // row 0 for column 0
+        if (!probe) { ts->part[0][lane] = m[0]; ts->part[1][lane] = x[0]; }
+        else ts->part[2][lane] = m[0];
+    }
+    if (threadIdx.x == 0) ts->bad = 0;
+    __syncthreads();
+    LSTAMP_INIT
+    for (int j = 0; j < n; ++j) {
+        const int par = (j & 1) * 4;
+        const double rowM = ts->part[par + (probe ? 2 : 0)][lane];
+        const double rowX = probe ? 0.0 : ts->part[par + 1][lane];
+        const double d = bcast_lane(rowM, j);
+        LSTAMP(13);
+        if (d > 0.0) {   // uniform
+            const double inv = nr_rcp(d);
+#pragma unroll
+            for (int g = 0; g < 2; ++g) {
+                if (sub + 32 * g + 24 > j) {   // own rows sub + 8 t, t = 4 g + u: the group is dead once its last row <= j
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int tt = 4 * g + u, i = sub + 8 * tt;
+                        const double l = bcast_lane(m[tt], j) * inv;
+                        if (i > j) {
+                            m[tt] = fma(-l, rowM, m[tt]);
+                            if (!probe) x[tt] = fma(-l, rowX, x[tt]);
+                            if (i == j + 1) {
+                                if (!probe) { ts->part[par ^ 4][lane] = m[tt]; ts->part[(par ^ 4) + 1][lane] = x[tt]; }
+                                else ts->part[(par ^ 4) + 2][lane] = m[tt];
+                            }
+                        }
+                    }
+                }
+            }
+        } else if (lane == 0) {
+            ts->bad = 1;
+        }
+        LSTAMP(14);
+        __syncthreads();
+        if (ts->bad) return false;
+        LSTAMP(15);
+    }
+    if (!probe) {
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+            const int i = sub + 8 * t;
+            if (i < n) {
+                const double rs = nr_rsqrt(bcast_lane(m[t], i));   // d_i: row i was final after column i - 1
+                if (in) W[lane * ld + i] = x[t] * rs;               // X is lower triangular: zeros above the diagonal of W'
+            }
+        }
+    }
+    __syncthreads();
+    return true;
 }
 
 // A: symmetric n x n (destroyed; on success its columns hold the eigenvectors, ascending eigenvalues in
-// ts->lam).  Q, X: n x n work matrices (same stride).  Returns false (uniformly) when the result must not be
+// ts->lam).  Q (ends up holding Q'), X: n x n work matrices (same stride).  Returns false (uniformly) when the result must not be
 // used; the caller then solves its own copy of A by Jacobi.  blockDim.x == 1024.
-__device__ bool tridiag_eigh(double* A, double* Q, double* X, int n, int ld, TriShared* ts, double orth_tol) {
+__device__ __forceinline__ bool tridiag_eigh(double* A, double* Q, double* X, int n, int ld, TriShared* ts, double orth_tol) {
     const int tid = threadIdx.x, nt = blockDim.x, lane = tid & 63, wave = tid >> 6;
     if (n == 1) {
         if (tid == 0) { ts->lam[0] = A[0]; A[0] = 1.0; }
         __syncthreads();
         return true;
     }
+    if (ld != kTriLd) return false;
     TSTAMP_INIT
-    for (int i = tid; i < n * n; i += nt) Q[(i / n) * ld + (i % n)] = (i / n == i % n) ? 1.0 : 0.0;
     if (tid == 0) ts->bad = 0;
     __syncthreads();
     TSTAMP(0);
-    // ---- (1) tridiagonalisation.  Two barriers per column: every wave forms the reflector itself (same inputs,
-    // same instructions, hence the same bits; all of them write the one copy of v), the products A v and Q v take 8
-    // lanes per row, and the updates have a fixed owner: thread (r0 = tid / 64, c = tid % 64) holds rows r0 + 16 q.
-    const int own_c = lane, own_r0 = wave;
-    for (int k = 0; k + 2 < n; ++k) {
-        const int m = n - k - 1;
-        const double xi = lane < m ? A[(k + 1 + lane) * ld + k] : 0.0;
-        const double sigma = wave_sum_all(lane >= 1 ? xi * xi : 0.0);
-        const double alpha = __shfl(xi, 0, 64);
-        double tau = 0.0, beta = alpha, scal = 0.0;
-        if (sigma != 0.0) {   // uniform
-            const double h2 = fma(alpha, alpha, sigma);
-            const double rs = nr_rsqrt(h2);
-            beta = -copysign(h2 * rs, alpha);
-            tau = (beta - alpha) * -copysign(rs, alpha);   // (beta - alpha) / beta
-            scal = nr_rcp(alpha - beta);
-        }
-        const double vl = lane < m ? (lane == 0 ? 1.0 : xi * scal) : 0.0;
-        ts->vv[lane] = vl;   // lane < 64 = kTriMax: the tail is zero
-        if (tid == 0) { ts->e[k] = beta; ts->d[k] = A[k * ld + k]; }
-        TSTAMP(1);
-        if (tau != 0.0) {   // uniform
-            {   // p_raw = A22 v (rows 0 .. m-1), u = Q[:, k+1:] v (rows m .. m+n-1): 8 lanes per row
-                const int row = tid >> 3, part = tid & 7;
-                const double* src = row < m ? A + (k + 1 + row) * ld + k + 1 : Q + (row < m + n ? row - m : 0) * ld + k + 1;
-                double acc = 0.0;
-                if (row < m + n)
-                    for (int c = part; c < m; c += 8) acc = fma(src[c], ts->vv[c], acc);
-                acc = sum8_dpp(acc);
-                if (part == 0) {
-                    if (row < m) ts->praw[row] = acc;
-                    else if (row < m + n) ts->uq[row - m] = acc;
-                }
-            }
-            __syncthreads();
-            TSTAMP(2);
-            // w = tau p_raw + al v with al = -tau/2 (tau p_raw . v)
-            const double pv = wave_sum_all(lane < m ? ts->praw[lane] * vl : 0.0);
-            const double al = -0.5 * tau * (tau * pv);
-            const int j = own_c - (k + 1);
-            const bool col_in = j >= 0 && own_c < n;
-            const double vj = col_in ? ts->vv[j] : 0.0;
-            const double wj = col_in ? fma(tau, ts->praw[j], al * vj) : 0.0;
-#pragma unroll
-            for (int q4 = 0; q4 < 4; ++q4) {
-                const int r = own_r0 + 16 * q4;
-                const int i = r - (k + 1);
-                if (col_in && r < n) {
-                    if (i >= 0) {
-                        const double vi = ts->vv[i];
-                        const double wi = fma(tau, ts->praw[i], al * vi);
-                        double* a = A + r * ld + own_c;
-                        *a = *a - (vi * wj + wi * vj);
-                    }
-                    double* qq = Q + r * ld + own_c;
-                    *qq = fma(-tau * ts->uq[r], vj, *qq);
-                }
-            }
-        }
-        __syncthreads();
-        TSTAMP(3);
-    }
-    if (tid == 0) {
-        if (n >= 2) { ts->d[n - 2] = A[(n - 2) * ld + n - 2]; ts->e[n - 2] = A[(n - 1) * ld + n - 2]; }
-        ts->d[n - 1] = A[(n - 1) * ld + n - 1];
-        ts->e[n - 1] = 0.0;
-    }
+    // ---- (1) tridiagonalisation
+    householder_phase(A, Q, n, ts);
+    TSTAMP(1);
     __syncthreads();
+    TSTAMP(2);
     {   // scale to |T| <= 1 by a power of two (exact), Gershgorin bounds of the scaled matrix: wave-parallel
         const double dl = lane < n ? ts->d[lane] : 0.0, el = lane < n ? ts->e[lane] : 0.0;
         double an = fmax(fabs(dl), fabs(el));
@@ -698,8 +901,8 @@ __device__ bool tridiag_eigh(double* A, double* Q, double* X, int n, int ld, Tri
         double sc = 1.0;
         if (an > 0.0 && an < 1e300) { int ex; (void)frexp(an, &ex); sc = ldexp(1.0, -ex); }
         const double ds = dl * sc, es = el * sc;
-        const double em = lane > 0 && lane < n ? fabs(ts->e[lane - 1]) * sc : 0.0;
-        const double rad = em + (lane + 1 < n ? fabs(es) : 0.0);
+        const double em = lane > 0 && lane < n ? ts->e[lane - 1] * sc : 0.0;
+        const double rad = fabs(em) + (lane + 1 < n ? fabs(es) : 0.0);
         double gl = lane < n ? ds - rad : 1e300, gu = lane < n ? ds + rad : -1e300;
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) {
@@ -708,7 +911,9 @@ __device__ bool tridiag_eigh(double* A, double* Q, double* X, int n, int ld, Tri
         }
         __syncthreads();   // every wave has read the unscaled d, e
         if (wave == 0) {
-            if (lane < n) { ts->d[lane] = ds; ts->e[lane] = es; ts->e2[lane] = es * es; }
+            if (lane < n) { ts->d[lane] = ds; ts->e[lane] = es; ts->de[lane] = make_double2(ds, em * em); }
+            else ts->de[lane] = make_double2(8.0, 0.0);
+            if (lane < 8) ts->de[kTriMax + lane] = make_double2(8.0, 0.0);
             if (lane == 0) {
                 if (!(an < 1e300)) ts->bad = 1;   // NaN / inf input
                 ts->scale = sc;
@@ -720,128 +925,199 @@ __device__ bool tridiag_eigh(double* A, double* Q, double* X, int n, int ld, Tri
         }
     }
     __syncthreads();
-    TSTAMP(4);
+    TSTAMP(3);
     if (ts->bad) return false;
-    // ---- (2) eigenvalues: eigenvalue i = tid / 4 is bracketed by 4 lanes (the first four waves, one per SIMD:
-    // the count is bound by instruction issue, so fewer trial points over more rounds cost less).  27 rounds: 5^27 = 2^62.7,
-    // the brackets end at rounding level (24 rounds left 4e-12 of orthogonality defect on a cond-1e4 matrix)
-    if (tid < 4 * kTriMax) {
-        const int i = tid >> 2, t = tid & 3;
+    // ---- (2) eigenvalues: eigenvalue i = tid / 8 is bracketed by 8 lanes (the first eight waves, two per SIMD).
+    // 20 rounds: 9^20 = 2^63.4, the brackets end at rounding level (2^55.7 left 4e-12 of orthogonality defect on a
+    // cond-1e4 matrix)
+    if (tid < 8 * kTriMax && wave * 8 < n) {
+        const int i = tid >> 3, t = tid & 7;
+        const int nblocks = (n + 7) >> 3;
         double lo = ts->gl, hi = ts->gu;
-        const bool live = i < n;
-        for (int it = 0; it < 27; ++it) {
-            const double x = lo + (hi - lo) * ((double)(t + 1) * 0.2);
-            const int c = live ? sturm_count(ts, n, x) : 0;
+        const double frac = (double)(t + 1) * (1.0 / 9.0);
+        for (int it = 0; it < 20; ++it) {
+            const double x = fma(hi - lo, frac, lo);
+            const int c = sturm_count(ts, nblocks, x);
             double nlo = c <= i ? x : lo, nhi = c > i ? x : hi;
             nlo = fmax(nlo, mov_dpp64<0xB1>(nlo)); nhi = fmin(nhi, mov_dpp64<0xB1>(nhi));
             nlo = fmax(nlo, mov_dpp64<0x4E>(nlo)); nhi = fmin(nhi, mov_dpp64<0x4E>(nhi));
+            nlo = fmax(nlo, mov_dpp64<0x141>(nlo)); nhi = fmin(nhi, mov_dpp64<0x141>(nhi));
             lo = nlo;
             hi = nhi;
         }
-        if (live && t == 0) ts->lam[i] = 0.5 * (lo + hi);
+        if (i < n && t == 0) ts->lam[i] = 0.5 * (lo + hi);
+    }
+    __syncthreads();
+    TSTAMP(4);
+    // ---- (3) eigenvectors of T, eigenvalue i = lane: wave 0 runs the forward pivots q_j (into X[:, i]), wave 1
+    // the backward pivots r_j (their reciprocals into A[:, i]); gamma_j = q_j - e_j^2 / r_{j+1} is smallest at the
+    // twist k; z_k = 1, z_j = -(e_j / q_j) z_{j+1} above it (wave 0), z_{j+1} = -(e_j / r_{j+1}) z_j below (wave 1).
+    // Every loop takes its rows eight at a time so that the LDS reads of a block are in flight together.
+    const double tiny = 1e-290;
+    double* Xc = X + (lane < n ? lane : 0);
+    double* Ac = A + (lane < n ? lane : 0);
+    const double lamb = ts->lam[lane < n ? lane : 0];
+    if (wave == 0 && lane < n) {
+        double q = ts->de[0].x - lamb;
+        Xc[0] = q;
+        for (int j0 = 1; j0 < n; j0 += 8) {
+            double2 r[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) r[u] = ts->de[j0 + u];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                if (j0 + u < n) {
+                    if (fabs(q) < tiny) q = -tiny;
+                    q = fma(-r[u].y, nr_rcp(q), r[u].x - lamb);
+                    Xc[(j0 + u) * ld] = q;
+                }
+            }
+        }
+    } else if (wave == 1 && lane < n) {
+        double r = ts->de[n - 1].x - lamb;
+        if (fabs(r) < tiny) r = -tiny;
+        double ir = nr_rcp(r);
+        Ac[(n - 1) * ld] = ir;
+        for (int j0 = n - 2; j0 >= 0; j0 -= 8) {
+            double dj[8], e2[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int j = j0 - u >= 0 ? j0 - u : 0;
+                dj[u] = ts->de[j].x;
+                e2[u] = ts->de[j + 1].y;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                if (j0 - u >= 0) {
+                    r = fma(-e2[u], ir, dj[u] - lamb);
+                    if (fabs(r) < tiny) r = -tiny;
+                    ir = nr_rcp(r);
+                    Ac[(j0 - u) * ld] = ir;
+                }
+            }
+        }
+    }
+    __syncthreads();
+    int kk = n - 1;
+    if (wave < 2 && lane < n) {
+        double gbest = fabs(Xc[(n - 1) * ld]);   // gamma_{n-1} = q_{n-1}
+        for (int j0 = n - 2; j0 >= 0; j0 -= 8) {
+            double g[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int j = j0 - u >= 0 ? j0 - u : 0;
+                g[u] = fabs(fma(-ts->de[j + 1].y, Ac[(j + 1) * ld], Xc[j * ld]));
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (j0 - u >= 0 && g[u] <= gbest) { gbest = g[u]; kk = j0 - u; }   // ties: the smallest index, in both waves alike
+        }
+    }
+    __syncthreads();   // both waves have read every q before the z overwrite them
+    if (wave == 0 && lane < n) {
+        double z = 1.0, nrm2 = 1.0;
+        for (int j0 = n - 2; j0 >= 0; j0 -= 8) {
+            double f[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int j = j0 - u >= 0 ? j0 - u : 0;
+                double qq = Xc[j * ld];
+                if (fabs(qq) < tiny) qq = -tiny;
+                f[u] = -(ts->e[j] * nr_rcp(qq));
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                if (j0 - u >= 0 && j0 - u < kk) {
+                    z = f[u] * z;
+                    Xc[(j0 - u) * ld] = z;
+                    nrm2 = fma(z, z, nrm2);
+                }
+            }
+        }
+        Xc[kk * ld] = 1.0;
+        ts->praw[lane] = nrm2;
+    } else if (wave == 1 && lane < n) {
+        double z = 1.0, nrm2 = 0.0;
+        for (int j0 = 0; j0 + 1 < n; j0 += 8) {
+            double f[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int j = j0 + u + 1 < n ? j0 + u : 0;
+                f[u] = -(ts->e[j] * Ac[(j + 1) * ld]);
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                if (j0 + u + 1 < n && j0 + u >= kk) {
+                    z = f[u] * z;
+                    Xc[(j0 + u + 1) * ld] = z;
+                    nrm2 = fma(z, z, nrm2);
+                }
+            }
+        }
+        ts->uq[lane] = nrm2;
+    }
+    __syncthreads();
+    if (tid < n) {
+        const double nrm2 = ts->praw[tid] + ts->uq[tid];
+        const bool ok = nrm2 > 0.0 && nrm2 < 1e300;
+        ts->inv[tid] = nr_rsqrt(ok ? nrm2 : 1.0);
+        if (!ok) ts->bad = 1;
     }
     __syncthreads();
     TSTAMP(5);
-    // ---- (3) eigenvectors of T, eigenvalue i = lane: wave 0 runs the forward pivots q_j (into X[:, i]), wave 1
-    // the backward pivots r_j (their reciprocals into A[:, i]); gamma_j = q_j - e_j^2 / r_{j+1} is smallest at the
-    // twist k; z_k = 1, z_j = -(e_j / q_j) z_{j+1} above it (wave 0), z_{j+1} = -(e_j / r_{j+1}) z_j below (wave 1)
-    const double tiny = 1e-290;
-    if (wave == 0 && lane < n) {
-        const double lamb = ts->lam[lane];
-        double q = ts->d[0] - lamb;
-        X[lane] = q;
-        for (int j = 1; j < n; ++j) {
-            if (fabs(q) < tiny) q = -tiny;
-            q = fma(-ts->e2[j - 1], nr_rcp(q), ts->d[j] - lamb);
-            X[j * ld + lane] = q;
-        }
-    } else if (wave == 1 && lane < n) {
-        const double lamb = ts->lam[lane];
-        double r = ts->d[n - 1] - lamb;
-        if (fabs(r) < tiny) r = -tiny;
-        double ir = nr_rcp(r);
-        A[(n - 1) * ld + lane] = ir;
-        for (int j = n - 2; j >= 0; --j) {
-            r = fma(-ts->e2[j], ir, ts->d[j] - lamb);
-            if (fabs(r) < tiny) r = -tiny;
-            ir = nr_rcp(r);
-            A[j * ld + lane] = ir;
-        }
-    }
-    __syncthreads();
-    if (wave < 2 && lane < n) {
-        int kk = n - 1;
-        double gbest = fabs(X[(n - 1) * ld + lane]);   // gamma_{n-1} = q_{n-1}
-        for (int j = n - 2; j >= 0; --j) {
-            const double g = fabs(fma(-ts->e2[j], A[(j + 1) * ld + lane], X[j * ld + lane]));
-            if (g <= gbest) { gbest = g; kk = j; }   // ties: the smallest index, in both waves alike
-        }
-        double z = 1.0, nrm2 = 0.0;
-        if (wave == 0) {
-            nrm2 = 1.0;
-            for (int j = kk - 1; j >= 0; --j) {
-                double qq = X[j * ld + lane];
-                if (fabs(qq) < tiny) qq = -tiny;
-                z = -(ts->e[j] * nr_rcp(qq)) * z;
-                X[j * ld + lane] = z;
-                nrm2 = fma(z, z, nrm2);
-            }
-            X[kk * ld + lane] = 1.0;
-            ts->praw[lane] = nrm2;
-        } else {
-            for (int j = kk; j + 1 < n; ++j) {
-                z = -(ts->e[j] * A[(j + 1) * ld + lane]) * z;
-                X[(j + 1) * ld + lane] = z;
-                nrm2 = fma(z, z, nrm2);
-            }
-            ts->uq[lane] = nrm2;
-        }
-    }
-    __syncthreads();
-    if (wave == 0 && lane < n) {
-        // normalise and take the residual |T x - lambda x|_inf in the same pass
-        const double lamb = ts->lam[lane];
-        const double nrm2 = ts->praw[lane] + ts->uq[lane];
-        const bool ok = nrm2 > 0.0 && nrm2 < 1e300;
-        const double inv = nr_rsqrt(ok ? nrm2 : 1.0);
-        double res = 0.0, xm = 0.0, x0 = X[lane] * inv, xp;
-        for (int j = 0; j < n; ++j) {
-            xp = j + 1 < n ? X[(j + 1) * ld + lane] * inv : 0.0;
-            const double tx = fma(ts->d[j] - lamb, x0, (j > 0 ? ts->e[j - 1] * xm : 0.0) + (j + 1 < n ? ts->e[j] * xp : 0.0));
-            res = fmax(res, fabs(tx));
-            X[j * ld + lane] = x0;
-            xm = x0;
-            x0 = xp;
-        }
-        if (!ok || !(res <= 1e-10)) ts->bad = 1;   // scaled matrix: |T| <= 1
-    }
-    __syncthreads();
-    TSTAMP(6);
-    if (ts->bad) return false;
-    // ---- orthogonality of X (clustered / repeated eigenvalues), then (4) Z = Q X into A
+    // ---- residuals |T x - lambda x|_inf of the normalised vectors and orthogonality of X (clustered / repeated
+    // eigenvalues), every thread / wave its share; then (4) Z = Q X into A
     {
         double worst = 0.0;
+        bool bad = false;
         for (int e0 = tid; e0 < n * n; e0 += nt) {
-            const int a = e0 / n, b = e0 - a * n;
-            if (b > a) continue;
-            double acc = 0.0;
-            for (int k = 0; k < n; ++k) acc = fma(X[k * ld + a], X[k * ld + b], acc);
-            worst = fmax(worst, fabs(acc - (a == b ? 1.0 : 0.0)));
+            const int j = e0 / n, i = e0 - j * n;
+            const double x0 = X[j * ld + i];
+            const double xm = j > 0 ? ts->e[j - 1] * X[(j - 1) * ld + i] : 0.0;
+            const double xp = j + 1 < n ? ts->e[j] * X[(j + 1) * ld + i] : 0.0;
+            const double tx = fma(ts->d[j] - ts->lam[i], x0, xm + xp) * ts->inv[i];
+            bad = bad || !(fabs(tx) <= 1e-10);   // scaled matrix: |T| <= 1
         }
+        const int jj = lane & 15, g = lane >> 4;
+        const int tiles = (n + 15) >> 4;
+        for (int t = wave; t < tiles * tiles; t += nt >> 6) {
+            const int a0 = (t / tiles) * 16, b0 = (t - (t / tiles) * tiles) * 16;
+            if (b0 > a0) continue;   // X'X is symmetric
+            const bool aok = a0 + jj < n, bok = b0 + jj < n;
+            const int ai = aok ? a0 + jj : 0, bi = bok ? b0 + jj : 0;
+            const double sa = ts->inv[ai], sb = ts->inv[bi];
+            tri_v4f64 acc = {0.0, 0.0, 0.0, 0.0};
+            for (int k0 = 0; k0 < n; k0 += 16) {
+                double a[4], b[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const bool kok = k0 + 4 * u + g < n;
+                    const int k = kok ? k0 + 4 * u + g : 0;
+                    a[u] = X[k * ld + ai] * sa;
+                    b[u] = X[k * ld + bi] * sb;
+                    if (!(aok && kok)) a[u] = 0.0;
+                    if (!(bok && kok)) b[u] = 0.0;
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[u], b[u], acc, 0, 0, 0);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = a0 + g + 4 * r, col = b0 + jj;
+                if (row < n && col < n) worst = fmax(worst, fabs(acc[r] - (row == col ? 1.0 : 0.0)));
+            }
+        }
+        if (bad) worst = 1e300;
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) worst = fmax(worst, __shfl_xor(worst, off, 64));
         if (lane == 0) ts->red[wave] = worst;
         __syncthreads();
         worst = 0.0;
         for (int w = 0; w < nt / 64; ++w) worst = fmax(worst, ts->red[w]);
-        if (!(worst <= orth_tol)) return false;
+        TSTAMP(6);
+        if (ts->bad || !(worst <= orth_tol)) return false;
     }
-    for (int e0 = tid; e0 < n * n; e0 += nt) {
-        const int r = e0 / n, c = e0 - r * n;
-        double acc = 0.0;
-        for (int k = 0; k < n; ++k) acc = fma(Q[r * ld + k], X[k * ld + c], acc);
-        A[r * ld + c] = acc;
-    }
+    mfma_mm<true, false>(A, Q, X, n, n, n, ld, ts->inv);   // Q holds Q'
     if (tid < n) ts->lam[tid] /= ts->scale;
     __syncthreads();
     TSTAMP(7);
@@ -854,29 +1130,34 @@ __device__ bool tridiag_eigh(double* A, double* Q, double* X, int n, int ld, Tri
 // Column j is never touched after step j - 1, so step j reads it (and the pivot) without a barrier of its own:
 // trailing update M[a][b] -= M[a][j] M[b][j] / d_j (lower triangle), X[i][c] -= (M[i][j] / d_j) X[j][c].
 // On success the diagonal of Mq holds D and its strict lower triangle the UNSCALED columns (L[i][j] d_j).
-__device__ bool ldl_inverse_pair(double* Mp, double* Mq, double* X, int n, int ld) {
-    const int tid = threadIdx.x, nt = blockDim.x;
+__device__ __forceinline__ bool ldl_inverse_pair(double* Mp, double* Mq, double* X, int n, int ld) {
+    // thread (ty, tx) owns column tx of the rows ty, ty + nty, ...: no index arithmetic beyond adds, and the strict
+    // upper triangle of the trailing matrices is never touched
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6, nty = blockDim.x >> 6;
+    LSTAMP_INIT
     for (int j = 0; j < n; ++j) {
         const double pj = Mp[j * ld + j], qj = Mq[j * ld + j];
         if (!(pj > 0.0) || !(qj > 0.0)) return false;   // every thread reads the same two numbers
-        const double ip = 1.0 / pj, iq = 1.0 / qj;
-        const int m = n - j - 1;
-        for (int e = tid; e < m * m + m * (j + 1); e += nt) {
-            if (e < m * m) {
-                const int a = e / m, b = e - a * m;
-                if (b <= a) {
-                    const int ra = (j + 1 + a) * ld, rb = (j + 1 + b) * ld;
-                    Mp[ra + j + 1 + b] = fma(-(Mp[ra + j] * ip), Mp[rb + j], Mp[ra + j + 1 + b]);
-                    Mq[ra + j + 1 + b] = fma(-(Mq[ra + j] * iq), Mq[rb + j], Mq[ra + j + 1 + b]);
+        const double ip = nr_rcp(pj), iq = nr_rcp(qj);
+        LSTAMP(13);
+        for (int c = tx; c < n; c += 64) {
+            if (c > j) {   // trailing update, lower triangle: rows i >= c
+                const double pc = Mp[c * ld + j], qc = Mq[c * ld + j];
+                for (int i = ty; i < n; i += nty) {
+                    if (i >= c) {
+                        Mp[i * ld + c] = fma(-(Mp[i * ld + j] * ip), pc, Mp[i * ld + c]);
+                        Mq[i * ld + c] = fma(-(Mq[i * ld + j] * iq), qc, Mq[i * ld + c]);
+                    }
                 }
-            } else {
-                const int e2 = e - m * m;
-                const int a = e2 / (j + 1), c = e2 - a * (j + 1);
-                const int i = j + 1 + a;
-                X[i * ld + c] = fma(-(Mq[i * ld + j] * iq), X[j * ld + c], X[i * ld + c]);
+            } else {       // X[i][c] -= l_ij X[j][c] for the rows below j (X is lower triangular: c <= j)
+                const double xj = X[j * ld + c];
+                for (int i = ty; i < n; i += nty)
+                    if (i > j) X[i * ld + c] = fma(-(Mq[i * ld + j] * iq), xj, X[i * ld + c]);
             }
         }
+        LSTAMP(14);
         __syncthreads();
+        LSTAMP(15);
     }
     return true;
 }
@@ -885,34 +1166,6 @@ struct TicaWork {  // global scratch: four n*ld matrices, then ev[n], mean[n], i
     double *A, *V, *B1, *B2, *ev, *mean, *isc;
     int* order;
 };
-
-// C[i][j] = sum_k opA(i,k) * B[k][j]   (opA = A or A'), i < rows, j < cols, k < inner
-__device__ void small_mm(double* C, const double* A, bool transA, const double* B, int rows, int cols, int inner,
-                         int ld) {
-    // four output elements per trip: four independent FMA chains hide the fp64 latency
-    const int total = rows * cols, nt = blockDim.x;
-    for (int e0 = threadIdx.x; e0 < total; e0 += 4 * nt) {
-        int ia[4], ja[4];
-        double acc[4] = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int e = min(e0 + u * nt, total - 1);
-            ia[u] = e / cols;
-            ja[u] = e - ia[u] * cols;
-        }
-        for (int k = 0; k < inner; ++k) {
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const double av = transA ? A[k * ld + ia[u]] : A[ia[u] * ld + k];
-                acc[u] = fma(av, B[k * ld + ja[u]], acc[u]);
-            }
-        }
-#pragma unroll
-        for (int u = 0; u < 4; ++u)
-            if (e0 + u * nt < total) C[ia[u] * ld + ja[u]] = acc[u];
-    }
-    __syncthreads();
-}
 
 // moments = [M00 F*F][M0t F*F][sx F][sy F][T]   (centred by shift, unscaled)
 // scale   = per-feature divisor applied to the centred data (NULL -> 1)
@@ -939,6 +1192,7 @@ __global__ __launch_bounds__(kEigThreads) void tica_solve_kernel(
     const double* sy = sx + n;
     const double T = sy[n];
     const double w = 2.0 * T;
+    KSTAMP_INIT
     if (!(T > 0.0)) {
         if (tid == 0) *out_rank = 0;
         for (int i = tid; i < n; i += nt) { out_eig[i] = 0.0; out_mean[i] = 0.0; }
@@ -963,6 +1217,7 @@ __global__ __launch_bounds__(kEigThreads) void tica_solve_kernel(
         __syncthreads();
     };
     build_cov();
+    KSTAMP(8);
 
     // ---- whitening L with L' C00 L = I -------------------------------------------------
     // deeptime's spd_inv_split keeps the eigen-directions of C00 with |s| >= epsilon.  When
@@ -973,29 +1228,7 @@ __global__ __launch_bounds__(kEigThreads) void tica_solve_kernel(
     constexpr bool kFused = lds_mats == 4;   // fused LDL' + inverse (one barrier per column) and the tridiagonal solver
     bool full_rank;
     if (kFused && n <= kTriMax) {
-        for (int e = tid; e < n * n; e += nt) {
-            const int i = e / n, j = e - i * n;
-            B2[i * ld + j] = A[i * ld + j] - (i == j ? epsilon : 0.0);
-            V[i * ld + j] = A[i * ld + j];
-        }
-        __syncthreads();
-        for (int e = tid; e < n * n; e += nt) {
-            const int i = e / n, j = e - i * n;
-            A[i * ld + j] = i == j ? 1.0 : 0.0;
-        }
-        __syncthreads();
-        full_rank = ldl_inverse_pair(B2, V, A, n, ld);   // V = L D L' (C00), A = L^-1
-        if (full_rank) {
-            for (int e = tid; e < n * n; e += nt) {
-                const int i = e / n, j = e - i * n;
-                // G = L D^1/2, whitening = G^-T: (D^-1/2 L^-1)' is upper triangular
-                B2[i * ld + j] = j >= i ? A[j * ld + i] / sqrt(V[j * ld + j]) : 0.0;
-            }
-            __syncthreads();
-        } else {
-            __syncthreads();
-            build_cov();   // the attempt overwrote C00
-        }
+        full_rank = ldl_whiten_registers(A, B2, n, epsilon, &ts);   // B2 = whitening (upper triangular); C00 stays in A
     } else {
         for (int e = tid; e < n * n; e += nt) {
             const int i = e / n, j = e - i * n;
@@ -1016,6 +1249,7 @@ __global__ __launch_bounds__(kEigThreads) void tica_solve_kernel(
             build_cov();
         }
     }
+    KSTAMP(9);
     int rank;
     if (full_rank) {
         rank = n;
@@ -1057,13 +1291,14 @@ __global__ __launch_bounds__(kEigThreads) void tica_solve_kernel(
         __syncthreads();
     }
     // ---- Ct = L' C0t L: A <- C0t L, V <- L' A, A <- sym(V) ----
-    small_mm(A, B1, false, B2, n, rank, n, ld);
-    small_mm(V, B2, true, A, rank, rank, n, ld);
+    mfma_mm<false, false>(A, B1, B2, n, rank, n, ld);
+    mfma_mm<true, false>(V, B2, A, rank, rank, n, ld);
     for (int e = tid; e < rank * rank; e += nt) {
         const int i = e / rank, j = e - i * rank;
         A[i * ld + j] = 0.5 * (V[i * ld + j] + V[j * ld + i]);
     }
     __syncthreads();
+    KSTAMP(10);
     // eigenpairs of the whitened C0t: tridiagonal solver (fallback: Jacobi on the saved copy)
     const double* Vec = V;
     bool fast = false;
@@ -1085,27 +1320,22 @@ __global__ __launch_bounds__(kEigThreads) void tica_solve_kernel(
         for (int i = tid; i < rank; i += nt) wk.ev[i] = A[i * ld + i];
     }
     __syncthreads();
+    KSTAMP(11);
     sort_desc_abs(wk.ev, rank, wk.order);
     // ---- R = L Rt (sorted), canonical signs, kinetic map ----
-    for (int e = tid; e < n * rank; e += nt) {
-        const int i = e / rank, j = e - i * rank;
-        const int src = wk.order[j];
-        double a = 0.0;
-        for (int k = 0; k < rank; ++k) a = fma(B2[i * ld + k], Vec[k * ld + src], a);
-        B1[i * ld + j] = a;
-    }
-    __syncthreads();
+    mfma_mm<false, false>(B1, B2, Vec, n, rank, rank, ld);   // columns still in solver order
     canonical_signs(B1, n, rank, ld);
     for (int e = tid; e < n * n; e += nt) {
         const int i = e / n, j = e - i * n;
         double v = 0.0;
         if (j < rank) {
-            v = B1[i * ld + j];
+            v = B1[i * ld + wk.order[j]];
             if (kinetic_map) v *= wk.ev[wk.order[j]];
         }
         out_W[e] = v;
     }
     for (int j = tid; j < n; j += nt) out_eig[j] = j < rank ? wk.ev[wk.order[j]] : 0.0;
+    KSTAMP(12);
 }
 
 // Plain symmetric eigendecomposition (ascending eigenvalues), for tests and the
@@ -1230,15 +1460,9 @@ __global__ __launch_bounds__(kEigThreads) void onesided_eig_kernel(const double*
         P3[i * ld + j] = vec[i * ld + j] / sqrt(sqrt(wj));
     }
     __syncthreads();
-    for (int e = tid; e < n * n; e += nt) {   // S -> P0
-        const int i = e / n, j = e - i * n;
-        double a = 0.0;
-        for (int k = 0; k < n; ++k) a = fma(P3[i * ld + k], P3[j * ld + k], a);
-        P0[i * ld + j] = a;
-    }
-    __syncthreads();
-    small_mm(P2, P0, false, P1, n, n, n, ld);   // S Ct
-    small_mm(P3, P2, false, P0, n, n, n, ld);   // (S Ct) S'   (S is symmetric)
+    mfma_mm<false, true>(P0, P3, P3, n, n, n, ld);   // S -> P0
+    mfma_mm<false, false>(P2, P0, P1, n, n, n, ld);   // S Ct
+    mfma_mm<false, false>(P3, P2, P0, n, n, n, ld);   // (S Ct) S'   (S is symmetric)
     for (int e = tid; e < n * n; e += nt) {
         const int i = e / n, j = e - i * n;
         P0[i * ld + j] = 0.5 * (P3[i * ld + j] + P3[j * ld + i]);
@@ -1271,7 +1495,7 @@ msm_status msm_tica_solve(msm_ctx* ctx, const double* d_moments, const double* d
     MSM_REQUIRE(ctx, F >= 1 && F <= 2 * kMaxPairs, "msm_tica_solve: need 1 <= F <= %d (got %d)", 2 * kMaxPairs, F);
     MSM_REQUIRE(ctx, epsilon >= 0.0, "msm_tica_solve: epsilon must be >= 0");
     MSM_REQUIRE(ctx, d_moments && d_eigvals && d_coeffs && d_mean && d_rank, "msm_tica_solve: NULL pointer");
-    const int ld = F | 1;  // odd stride
+    const int ld = F <= kTriMax ? kTriLd : (F | 1);  // odd stride; the fixed one of the tridiagonal solver for F <= 64
     const size_t mat = (size_t)F * ld;
     const size_t need = (4 * mat + 3 * F) * sizeof(double) + (size_t)F * sizeof(int) + 64;
     msm_status rs = msm_reserve_scratch(ctx, need);
@@ -1299,7 +1523,7 @@ msm_status msm_onesided_tica_eigenvalues(msm_ctx* ctx, const double* d_moments, 
     MSM_REQUIRE(ctx, F >= 1 && F <= 2 * kMaxPairs, "msm_onesided_tica_eigenvalues: need 1 <= F <= %d (got %d)",
                 2 * kMaxPairs, F);
     MSM_REQUIRE(ctx, d_moments && d_eigvals && clip > 0.0, "msm_onesided_tica_eigenvalues: bad arguments");
-    const int ld = F | 1;
+    const int ld = F <= kTriMax ? kTriLd : (F | 1);
     const size_t mat = (size_t)F * ld;
     const size_t lds = 4 * mat * sizeof(double);
     const bool use_lds = lds <= 140 * 1024;
@@ -1323,7 +1547,7 @@ msm_status msm_eigh(msm_ctx* ctx, const double* d_a, int n, double* d_w, double*
     if (!ctx) return MSM_ERR_INVALID;
     MSM_REQUIRE(ctx, n >= 1 && n <= 2 * kMaxPairs, "msm_eigh: need 1 <= n <= %d (got %d)", 2 * kMaxPairs, n);
     MSM_REQUIRE(ctx, d_a && d_w, "msm_eigh: NULL pointer");
-    const int ld = n | 1;
+    const int ld = n <= kTriMax ? kTriLd : (n | 1);
     const size_t mat = (size_t)n * ld;
     msm_status rs = msm_reserve_scratch(ctx, 2 * mat * sizeof(double) + (size_t)n * sizeof(int) + 64);
     if (rs != MSM_OK) return rs;
