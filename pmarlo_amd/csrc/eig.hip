@@ -555,6 +555,7 @@ struct TriShared {
     int bad;
     double part[8][kTriMax];   // partial products of the tridiagonalisation, one row per working wave
     double2 vw[8][kTriMax];    // {v_j, w_j} of the column in flight, one copy per working wave
+    alignas(16) double lv[12][kTriMax];    // multipliers of the LDL' column in flight, one copy per working wave
 };
 
 typedef double tri_v4f64 __attribute__((ext_vector_type(4)));
@@ -799,74 +800,88 @@ __device__ __forceinline__ void householder_phase(double* A, double* QT, int n, 
 }
 
 // Whitening of a full-rank C00 in registers, the pattern of householder_phase: two LDL' eliminations side by side, one
-// barrier per column.  Waves 0-7 hold the rows i = w (mod 8) of C00 and of X (= identity at the start), waves 8-15 the
-// same rows of the probe C00 - epsilon I; lane = column.  Column j: the owner of row j has left it in the LDS; every
-// wave takes the pivot d_j from it, forms l_i = M[i][j] / d_j for its own rows (the entry sits in lane j: v_readlane) and
-// subtracts l_i x row j from row i of M and of X; the owner of row j + 1 leaves that row in the LDS for the next column.
+// barrier per column.  Waves 0-3 hold the rows i = w (mod 4) of C00, waves 4-7 the same rows of X (= identity at the
+// start), waves 8-11 those of the probe C00 - epsilon I; lane = column; 16 doubles per lane, compile-time indices only.
+// Column j: the owner of row j has left it in the LDS.  The trailing matrix is symmetric, so that row is also column j:
+// lane i of (row j) / d_j IS the multiplier l_i; every wave parks the multipliers in its own LDS copy, ordered so that
+// those of its sixteen rows come back as eight 16-byte broadcast reads.  Row i of M, X or the probe then takes one fma
+// (l_i = 0 up to row j: finished rows stay); the owner of row j + 1 leaves it in the LDS for the next column.  The SIMDs
+// issue about one instruction per 3.3-3.8 cycles between all their waves, so what counts per column is the instruction
+// total: 1.5 per row here.
 // On success W = (D^-1/2 L^-1)' (upper triangular, W' C00 W = I) is written to `W`; false (uniformly) as soon as a pivot
-// of either matrix is not positive.  C is left as it was.  blockDim.x == 1024.
+// of either matrix is not positive.  C is left as it was.  blockDim.x >= 768.
 __device__ __forceinline__ bool ldl_whiten_registers(const double* C, double* W, int n, double epsilon, TriShared* ts) {
     constexpr int ld = kTriLd;
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const bool in = lane < n;
-    const bool probe = wave >= 8;
-    const int sub = wave & 7;
-    double m[8], x[8];
+    const int what = wave >> 2;   // 0: C00, 1: X, 2: probe, 3: nothing
+    const int sub = wave & 3;
+    double m[16];
 #pragma unroll
-    for (int t = 0; t < 8; ++t) {
-        const int i = sub + 8 * t;
-        m[t] = (in && i < n) ? C[i * ld + lane] - (probe && lane == i ? epsilon : 0.0) : 0.0;
-        x[t] = lane == i ? 1.0 : 0.0;
+    for (int t = 0; t < 16; ++t) {
+        const int i = sub + 4 * t;
+        if (what == 1) m[t] = lane == i ? 1.0 : 0.0;
+        else m[t] = (what < 3 && in && i < n) ? C[i * ld + lane] - (what == 2 && lane == i ? epsilon : 0.0) : 0.0;
     }
-    if (sub == 0) {   // row 0 for column 0
-        if (!probe) { ts->part[0][lane] = m[0]; ts->part[1][lane] = x[0]; }
-        else ts->part[2][lane] = m[0];
-    }
-    if (threadIdx.x == 0) ts->bad = 0;
+    if (sub == 0 && what < 3) ts->part[what][lane] = m[0];   // row 0 for column 0
     __syncthreads();
     LSTAMP_INIT
     for (int j = 0; j < n; ++j) {
         const int par = (j & 1) * 4;
-        const double rowM = ts->part[par + (probe ? 2 : 0)][lane];
-        const double rowX = probe ? 0.0 : ts->part[par + 1][lane];
-        const double d = bcast_lane(rowM, j);
-        LSTAMP(13);
-        if (d > 0.0) {   // uniform
-            const double inv = nr_rcp(d);
+        if (what < 3) {
+            // row j of the matrix the multipliers come from, of the matrix this wave updates, and of the other
+            // elimination: every wave sees both pivots, so all of them leave together when one is not positive
+            const double rowM = ts->part[par + (what == 2 ? 2 : 0)][lane];
+            const double row = what == 1 ? ts->part[par + 1][lane] : rowM;
+            const double rowO = ts->part[par + (what == 2 ? 0 : 2)][lane];
+            const double d = bcast_lane(rowM, j), dO = bcast_lane(rowO, j);
+            LSTAMP(13);
+            if (!(d > 0.0) || !(dO > 0.0)) return false;   // uniform over the workgroup (see below for the idle waves)
+            {
+                // multipliers of the live rows (zero up to row j: finished rows stay as they are), dealt out so that
+                // the sixteen of this wave's rows lie side by side in its LDS copy: l_i at (i mod 4) * 16 + i / 4
+                const double lvec = lane > j ? rowM * nr_rcp(d) : 0.0;
+                double* lv = ts->lv[wave];
+                lv[(lane & 3) * 16 + (lane >> 2)] = lvec;
+                const double2* mine = reinterpret_cast<const double2*>(lv + sub * 16);
 #pragma unroll
-            for (int g = 0; g < 2; ++g) {
-                if (sub + 32 * g + 24 > j) {   // own rows sub + 8 t, t = 4 g + u: the group is dead once its last row <= j
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        const int tt = 4 * g + u, i = sub + 8 * tt;
-                        const double l = bcast_lane(m[tt], j) * inv;
-                        if (i > j) {
-                            m[tt] = fma(-l, rowM, m[tt]);
-                            if (!probe) x[tt] = fma(-l, rowX, x[tt]);
-                            if (i == j + 1) {
-                                if (!probe) { ts->part[par ^ 4][lane] = m[tt]; ts->part[(par ^ 4) + 1][lane] = x[tt]; }
-                                else ts->part[(par ^ 4) + 2][lane] = m[tt];
-                            }
-                        }
+                for (int t2 = 0; t2 < 8; ++t2) {
+                    const double2 l = mine[t2];
+                    m[2 * t2] = fma(-l.x, row, m[2 * t2]);
+                    m[2 * t2 + 1] = fma(-l.y, row, m[2 * t2 + 1]);
+                }
+                if (((j + 1 - sub) & 3) == 0) {   // this wave owns row j + 1: leave it for the next column
+                    double* dst = ts->part[(par ^ 4) + what] + lane;
+                    switch ((j + 1 - sub) >> 2) {
+                        case 0: *dst = m[0]; break;   case 1: *dst = m[1]; break;   case 2: *dst = m[2]; break;
+                        case 3: *dst = m[3]; break;   case 4: *dst = m[4]; break;   case 5: *dst = m[5]; break;
+                        case 6: *dst = m[6]; break;   case 7: *dst = m[7]; break;   case 8: *dst = m[8]; break;
+                        case 9: *dst = m[9]; break;   case 10: *dst = m[10]; break; case 11: *dst = m[11]; break;
+                        case 12: *dst = m[12]; break; case 13: *dst = m[13]; break; case 14: *dst = m[14]; break;
+                        case 15: *dst = m[15]; break; default: break;
                     }
                 }
             }
-        } else if (lane == 0) {
-            ts->bad = 1;
+        } else {   // waves without rows: the same two pivots, the same decision
+            const double dM = ts->part[par][j], dP = ts->part[par + 2][j];
+            if (!(dM > 0.0) || !(dP > 0.0)) return false;
         }
         LSTAMP(14);
         __syncthreads();
-        if (ts->bad) return false;
         LSTAMP(15);
     }
-    if (!probe) {
+    // d_i sits in lane i of row i of the C00 waves (row i was final after column i - 1): hand D^-1/2 to the X waves
+    if (what == 0) {
 #pragma unroll
-        for (int t = 0; t < 8; ++t) {
-            const int i = sub + 8 * t;
-            if (i < n) {
-                const double rs = nr_rsqrt(bcast_lane(m[t], i));   // d_i: row i was final after column i - 1
-                if (in) W[lane * ld + i] = x[t] * rs;               // X is lower triangular: zeros above the diagonal of W'
-            }
+        for (int t = 0; t < 16; ++t)
+            if (lane == sub + 4 * t && lane < n) ts->inv[lane] = nr_rsqrt(m[t]);
+    }
+    __syncthreads();
+    if (what == 1 && in) {
+#pragma unroll
+        for (int t = 0; t < 16; ++t) {
+            const int i = sub + 4 * t;
+            if (i < n) W[lane * ld + i] = m[t] * ts->inv[i];   // X is lower triangular: zeros above the diagonal of W'
         }
     }
     __syncthreads();

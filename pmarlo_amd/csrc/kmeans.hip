@@ -823,9 +823,11 @@ template <typename T>
 msm_status launch_pack(msm_ctx* ctx, const T* x, int64_t n, int d, int64_t ld, const double* mean, const double* stdv,
                        uint4* image) {
     const unsigned grid = (unsigned)((n + 255) / 256);
+    const int dense = ld == d && ((uintptr_t)x & 15) == 0;
 #define MSM_PACK_CASE(D)                                                                                              \
     case D:                                                                                                           \
-        hipLaunchKernelGGL((kmeans_pack_kernel<T, D>), dim3(grid), dim3(256), 0, ctx->stream, x, n, ld, mean, stdv, image); \
+        hipLaunchKernelGGL((kmeans_pack_kernel<T, D>), dim3(grid), dim3(256), 0, ctx->stream, x, n, ld, mean, stdv, image, \
+                           dense);                                                                                    \
         break
     switch (d) {
         MSM_PACK_CASE(1); MSM_PACK_CASE(2); MSM_PACK_CASE(3); MSM_PACK_CASE(4); MSM_PACK_CASE(5);

@@ -79,37 +79,46 @@ __device__ __forceinline__ float med3_f32(float a, float b, float c) { return __
 // three parts of -(1 - kappa) h_j), the LAST slot = |x| rounded up (it meets kappa |c_j|), +inf when the frame
 // fails the range guard.  One thread per frame.
 // ---------------------------------------------------------------------------------------------------------
+// Both sides of the kernel go through the LDS so that the memory system only ever sees consecutive lanes on
+// consecutive 16-byte pieces: a lane reading its own 8 D-byte row or writing its own 64 NM-byte image row touched 64
+// cache lines per instruction (61 us for 208 MB at C3).  `dense`: rows back to back (ld == D) on a 16-byte boundary.
 template <typename T, int D>
 __global__ __launch_bounds__(256) void kmeans_pack_kernel(const T* __restrict__ x, int64_t n, int64_t ld,
                                                          const double* __restrict__ mean,
-                                                         const double* __restrict__ stdv, uint4* __restrict__ image) {
+                                                         const double* __restrict__ stdv, uint4* __restrict__ image,
+                                                         int dense) {
     constexpr int NM = filter_nm(D);
-    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (t >= n) return;
-    const T* row = x + t * ld;
-    unsigned part[D][3];
-    double q = 0.0;
-    bool ok = true;
+    constexpr int kOutStride = 4 * NM + 1;              // uint4 per staged image row: one of padding (bank spread)
+    constexpr int kInBytes = 256 * D * (int)sizeof(T);  // a workgroup's rows, back to back
+    constexpr int kOutBytes = 256 * kOutStride * 16;
+    __shared__ __attribute__((aligned(16))) unsigned char stage[kOutBytes > kInBytes ? kOutBytes : kInBytes];
+    const int64_t t0 = (int64_t)blockIdx.x * 256;
+    const int64_t t = t0 + threadIdx.x;
+    const int rows = (int)(n - t0 < 256 ? n - t0 : 256);
     double v[D];
-    if constexpr (sizeof(T) == 8 && D % 2 == 0) {
-        // fp64 rows of an even width on 16-byte boundaries: D / 2 vector loads (the scalar form cost 4x the bytes
-        // at the memory side: neighbouring lanes share every 128-byte line)
-        if (((ld * sizeof(T)) & 15) == 0 && (((uintptr_t)x) & 15) == 0) {
-            const double2* r2 = reinterpret_cast<const double2*>(row);
-#pragma unroll
-            for (int f2 = 0; f2 < D / 2; ++f2) {
-                const double2 w = r2[f2];
-                v[2 * f2] = w.x;
-                v[2 * f2 + 1] = w.y;
-            }
-        } else {
-#pragma unroll
-            for (int f = 0; f < D; ++f) v[f] = load_as_f64(row + f);
+    if (dense) {
+        // rows * D * sizeof(T) bytes from x + t0 * D, 16 bytes per lane and trip (the tail of the last workgroup by element)
+        const unsigned char* src = reinterpret_cast<const unsigned char*>(x + t0 * D);
+        const int nbytes = rows * D * (int)sizeof(T);
+        for (int b = threadIdx.x * 16; b + 16 <= nbytes; b += 256 * 16)
+            *reinterpret_cast<uint4*>(stage + b) = *reinterpret_cast<const uint4*>(src + b);
+        if (threadIdx.x < (nbytes & 15) / (int)sizeof(T)) {
+            const int e = (nbytes & ~15) / (int)sizeof(T) + threadIdx.x;
+            reinterpret_cast<T*>(stage)[e] = reinterpret_cast<const T*>(src)[e];
         }
+        __syncthreads();
+        const T* row = reinterpret_cast<const T*>(stage) + threadIdx.x * D;
+#pragma unroll
+        for (int f = 0; f < D; ++f) v[f] = threadIdx.x < rows ? (double)row[f] : 0.0;
+        __syncthreads();   // the staging area is reused for the images
     } else {
+        const T* row = x + (t < n ? t : n - 1) * ld;
 #pragma unroll
         for (int f = 0; f < D; ++f) v[f] = load_as_f64(row + f);
     }
+    unsigned part[D][3];
+    double q = 0.0;
+    bool ok = true;
 #pragma unroll
     for (int f = 0; f < D; ++f) {
         if (mean) v[f] = (v[f] - mean[f]) / stdv[f];
@@ -132,11 +141,15 @@ __global__ __launch_bounds__(256) void kmeans_pack_kernel(const T* __restrict__ 
         else if (s == 32 * NM - 1) val = xn;              // |x| rounded up against kappa |c_j|
         slots[s] = val;
     }
-    uint4* dst = image + t * (4 * NM);
+    uint4* mine = reinterpret_cast<uint4*>(stage) + threadIdx.x * kOutStride;
 #pragma unroll
     for (int c = 0; c < 4 * NM; ++c)
-        dst[c] = make_uint4(slots[8 * c + 0] | (slots[8 * c + 1] << 16), slots[8 * c + 2] | (slots[8 * c + 3] << 16),
-                            slots[8 * c + 4] | (slots[8 * c + 5] << 16), slots[8 * c + 6] | (slots[8 * c + 7] << 16));
+        mine[c] = make_uint4(slots[8 * c + 0] | (slots[8 * c + 1] << 16), slots[8 * c + 2] | (slots[8 * c + 3] << 16),
+                             slots[8 * c + 4] | (slots[8 * c + 5] << 16), slots[8 * c + 6] | (slots[8 * c + 7] << 16));
+    __syncthreads();
+    uint4* dst = image + t0 * (4 * NM);
+    for (int c = threadIdx.x; c < rows * 4 * NM; c += 256)
+        dst[c] = reinterpret_cast<const uint4*>(stage)[(c / (4 * NM)) * kOutStride + (c % (4 * NM))];
 }
 
 // ---------------------------------------------------------------------------------------------------------

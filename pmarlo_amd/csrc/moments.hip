@@ -264,6 +264,16 @@ __global__ __launch_bounds__(kThreads) void project_mfma_kernel(
     }
     for (int f = threadIdx.x; f < F16; f += kThreads) mul[f] = f < F ? mu[f] : 0.0;
     __syncthreads();
+    // accumulator start of output column c: -(m2 . W'[:, c]), once per workgroup (every lane used to walk the F
+    // rows of W itself: 8 F global loads per lane before the first frame)
+    double* a0 = mul + F16;   // [16]
+    if (threadIdx.x < 16) {
+        double a = 0.0;
+        if (m2 && threadIdx.x < d)
+            for (int f = 0; f < F; ++f) a = fma(m2[f], W[(size_t)f * ldw + threadIdx.x], a);
+        a0[threadIdx.x] = -a;
+    }
+    __syncthreads();
 
     const int lane = threadIdx.x & 63;
     const int j = lane & 15, g = lane >> 4;
@@ -273,17 +283,9 @@ __global__ __launch_bounds__(kThreads) void project_mfma_kernel(
     const int n_chunks = (F16 + kPChunk - 1) / kPChunk;
 
     // accumulator start: -(m2 . W[:, c]) for this lane's 4 output columns c = g + 4r
-    v4f64 acc0 = {0.0, 0.0, 0.0, 0.0};
-    if (m2) {
+    v4f64 acc0;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int c = g + 4 * r;
-            double a = 0.0;
-            if (c < d)
-                for (int f = 0; f < F; ++f) a = fma(m2[f], W[(size_t)f * ldw + c], a);
-            acc0[r] = -a;
-        }
-    }
+    for (int r = 0; r < 4; ++r) acc0[r] = a0[g + 4 * r];
     auto store = [&](int64_t grp, const v4f64& acc) {
         const int64_t t = grp * 16 + j;
         if (t < n) {
@@ -468,16 +470,22 @@ msm_status msm_project(msm_ctx* ctx, const void* d_x, msm_dtype dtype, int64_t n
     MSM_REQUIRE(ctx, dtype == MSM_F32 || dtype == MSM_F64, "msm_project: bad dtype");
     if (n == 0) return MSM_OK;
     MSM_REQUIRE(ctx, d_x && d_mu && d_inv_sigma && d_w && d_y, "msm_project: NULL pointer");
-    if (d <= 16 && (size_t)((F + 15) & ~15) * 17 * sizeof(double) <= 48 * 1024) {
+    if (d <= 16 && ((size_t)((F + 15) & ~15) * 17 + 16) * sizeof(double) <= 48 * 1024) {
         const int64_t n_groups = (n + 15) / 16;
-        const int grid = (int)std::min<int64_t>((n_groups + 3) / 4, (int64_t)ctx->n_cu * 8);
         const size_t esz = dtype == MSM_F32 ? 4 : 8;
         const int F16 = (F + 15) & ~15;
-        const size_t plds = (size_t)F16 * 17 * sizeof(double);
+        const size_t plds = ((size_t)F16 * 17 + 16) * sizeof(double);
         const bool vec = (F % 16 == 0) && (ld % 4 == 0) && (((uintptr_t)d_x) % (4 * esz) == 0);
+        // one wave of workgroups: exactly as many as are resident at once (a grid of 8 per CU ran a second, thin round
+        // behind the 6 per CU the registers allow)
 #define MSM_PROJ(T, V)                                                                                         \
-        hipLaunchKernelGGL((project_mfma_kernel<T, V>), dim3(grid), dim3(kThreads), plds, ctx->stream, (const T*)d_x, n, \
-                           F, ld, d_mu, d_inv_sigma, d_mean2, d_w, d, ldw, d_y, ldy, bits)
+        do {                                                                                                   \
+            int per_cu = 0;                                                                                    \
+            MSM_HIP(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, project_mfma_kernel<T, V>, kThreads, plds)); \
+            const int grid = (int)std::min<int64_t>((n_groups + 3) / 4, (int64_t)ctx->n_cu * std::max(per_cu, 1)); \
+            hipLaunchKernelGGL((project_mfma_kernel<T, V>), dim3(grid), dim3(kThreads), plds, ctx->stream, (const T*)d_x, n, \
+                               F, ld, d_mu, d_inv_sigma, d_mean2, d_w, d, ldw, d_y, ldy, bits);                \
+        } while (0)
         if (dtype == MSM_F32) { if (vec) MSM_PROJ(float, true); else MSM_PROJ(float, false); }
         else { if (vec) MSM_PROJ(double, true); else MSM_PROJ(double, false); }
 #undef MSM_PROJ
