@@ -115,6 +115,24 @@ msm_status msm_featurize_dihedrals(msm_ctx* ctx, const float* d_xyz, int64_t n, 
                                    const int32_t* d_quads, int Q, int mode, float* d_out, int64_t ld,
                                    int col_off);
 
+/* Structure features whose reference implementation is an mdtraj algorithm (S/features/builtins.py:171-250: the
+ * built-ins "sasa", "hbonds_count", "ssfrac", all three in the default feature set of S/api/features.py:378).
+ *   sasa: Shrake-Rupley accessible area per atom, float32 [n, A] (nm^2), as mdtraj.shrake_rupley computes it
+ *         (geometry/src/sasa.cpp) before its per-residue sums: d_radii float32 [A] = atomic radius + probe radius,
+ *         d_points float32 [P, 3] = the unit sphere points (golden spiral), fp32 throughout.
+ *   hbond presence: for every (donor, hydrogen, acceptor) row of d_triplets int32 [Tn, 3] the number of frames with
+ *         |H - A| < dist_cutoff and angle(D, H, A) > angle_cutoff (radians), the two criteria of
+ *         mdtraj.baker_hubbard (geometry/hbond.py); the frequency threshold is the caller's.
+ *   dssp: Kabsch-Sander secondary structure per frame and residue (mdtraj.compute_dssp, geometry/src/dssp.cpp):
+ *         d_backbone int32 [R, 4] = atom indices of N, CA, C, O of each protein residue, d_chain int32 [R],
+ *         d_proline uint8 [R]; d_codes uint8 [n, R]: 0 loop, 1 H, 2 B, 3 E, 4 G, 5 I, 6 T, 7 S. */
+msm_status msm_featurize_sasa(msm_ctx* ctx, const float* d_xyz, int64_t n, int A, const float* d_radii,
+                              const float* d_points, int P, float* d_out);
+msm_status msm_hbond_presence(msm_ctx* ctx, const float* d_xyz, int64_t n, int A, const int32_t* d_triplets,
+                              int Tn, float dist_cutoff, float angle_cutoff, uint64_t* d_counts);
+msm_status msm_dssp(msm_ctx* ctx, const float* d_xyz, int64_t n, int A, const int32_t* d_backbone,
+                    const int32_t* d_chain, const uint8_t* d_proline, int R, uint8_t* d_codes);
+
 /* ------------------------------------------------------------------ */
 /* lag-tau transition counts                                            */
 /* ------------------------------------------------------------------ */

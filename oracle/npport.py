@@ -1226,3 +1226,234 @@ def ck_mixin_select_lag(dtrajs, n_states, taus, factor=2):
     if best == 1 and 2 in taus and mses[taus.index(2)] <= min(mses) + 1e-12:
         best = 2
     return best, mses
+
+
+# ---------------------------------------------------------------------------------------------------------
+# Structure features (S/features/builtins.py:171-250 call mdtraj; mdtraj is absent from the container, so these
+# restate mdtraj 1.10's published algorithms -- parity with mdtraj itself unpinned): Shrake-Rupley
+# (geometry/src/sasa.cpp), Baker-Hubbard (geometry/hbond.py) and DSSP (geometry/src/dssp.cpp, a port of DSSP 2.0).
+# ---------------------------------------------------------------------------------------------------------
+def sasa_sphere_points(n_points):
+    """sasa.cpp generate_sphere_points: golden-section spiral, float32."""
+    i = np.arange(n_points, dtype=np.float64)
+    inc = np.pi * (3.0 - np.sqrt(5.0))
+    offset = 2.0 / n_points
+    y = i * offset - 1.0 + offset / 2.0
+    r = np.sqrt(1.0 - y * y)
+    phi = i * inc
+    return np.stack([np.cos(phi) * r, y, np.sin(phi) * r], axis=1).astype(np.float32)
+
+
+def shrake_rupley_atoms(xyz, radii, n_sphere_points=960):
+    """Per-atom accessible areas, float32 (n_frames, n_atoms): sasa.cpp asa_frame in fp32 operation order
+    (`radii` already include the probe radius)."""
+    xyz = np.asarray(xyz, np.float32)
+    radii = np.asarray(radii, np.float32)
+    pts = sasa_sphere_points(n_sphere_points)
+    n, A, _ = xyz.shape
+    out = np.zeros((n, A), np.float32)
+    const = np.float32(4.0 * np.pi / n_sphere_points)
+
+    def dot3(d):   # (x x + y y) + z z in float32
+        return (d[..., 0] * d[..., 0] + d[..., 1] * d[..., 1]) + d[..., 2] * d[..., 2]
+
+    for t in range(n):
+        fr = xyz[t]
+        for i in range(A):
+            d = fr[i] - fr                                   # r_i - r_j
+            cut = radii[i] + radii
+            nb = np.nonzero((dot3(d) < cut * cut) & (np.arange(A) != i))[0]
+            centered = fr[i] + radii[i] * pts                # float32: multiply, then add
+            if len(nb):
+                dd = centered[:, None, :] - fr[nb][None, :, :]
+                inside = (dot3(dd) < (radii[nb] * radii[nb])[None, :]).any(axis=1)
+                n_acc = int((~inside).sum())
+            else:
+                n_acc = len(pts)
+            out[t, i] = const * radii[i] * radii[i] * np.float32(n_acc)
+    return out
+
+
+def baker_hubbard_presence(xyz, triplets, distance_cutoff=0.25, angle_cutoff=2.0 * np.pi / 3.0):
+    """hbond.py _compute_bounded_geometry + baker_hubbard: frames in which each triplet meets both criteria."""
+    xyz = np.asarray(xyz, np.float32)
+    trip = np.asarray(triplets, int).reshape(-1, 3)
+
+    def dist(i, j):
+        d = xyz[:, j, :] - xyz[:, i, :]
+        return np.sqrt((d[..., 0] * d[..., 0] + d[..., 1] * d[..., 1]) + d[..., 2] * d[..., 2]).astype(np.float32)
+
+    a = dist(trip[:, 0], trip[:, 1])     # D - H
+    b = dist(trip[:, 1], trip[:, 2])     # H ... A
+    c = dist(trip[:, 2], trip[:, 0])     # A ... D
+    with np.errstate(invalid="ignore", divide="ignore"):
+        cosines = (a * a + b * b - c * c) / (np.float32(2.0) * a * b)
+    np.clip(cosines, -1, 1, out=cosines)
+    angles = np.arccos(cosines)
+    presence = (b < np.float32(distance_cutoff)) & (angles > np.float32(angle_cutoff))
+    return presence.sum(axis=0).astype(np.int64)
+
+
+def dssp_codes(xyz, backbone, chain, proline):
+    """Kabsch-Sander assignment per frame and protein residue, uint8 (n_frames, R): 0 loop, 1 H, 2 B, 3 E, 4 G, 5 I,
+    6 T, 7 S.  dssp.cpp / DSSP 2.0 structure.cpp step by step (fp32 geometry in Angstrom)."""
+    xyz = np.asarray(xyz, np.float32)
+    bb = np.asarray(backbone, int).reshape(-1, 4)
+    chain = np.asarray(chain, int)
+    proline = np.asarray(proline, bool)
+    R = bb.shape[0]
+    n = xyz.shape[0]
+    out = np.zeros((n, R), np.uint8)
+    f32 = np.float32
+
+    def dist(a, b):
+        d = a - b
+        return np.sqrt((d[0] * d[0] + d[1] * d[1]) + d[2] * d[2])
+
+    for t in range(n):
+        fr = xyz[t] * f32(10.0)
+        N, CA, C, O = (fr[bb[:, k]] for k in range(4))
+        H = N.copy()
+        for r in range(1, R):
+            if not proline[r] and chain[r - 1] == chain[r]:
+                H[r] = N[r] + (C[r - 1] - O[r - 1]) / dist(C[r - 1], O[r - 1])
+
+        def no_break(a, b):
+            for r in range(a, b):
+                if chain[r] != chain[r + 1] or dist(C[r], N[r + 1]) > f32(2.5):
+                    return False
+            return True
+
+        acc = [[-1, -1] for _ in range(R)]
+        en = [[f32(0.0), f32(0.0)] for _ in range(R)]
+
+        def energy(donor, acceptor):
+            res = f32(0.0)
+            if not proline[donor]:
+                dHO, dHC = dist(H[donor], O[acceptor]), dist(H[donor], C[acceptor])
+                dNC, dNO = dist(N[donor], C[acceptor]), dist(N[donor], O[acceptor])
+                if min(dHO, dHC, dNC, dNO) < f32(0.5):
+                    res = f32(-9.9)
+                else:
+                    k = f32(27.888)
+                    res = -k / dHO + k / dHC - k / dNC + k / dNO
+                res = f32(_roundf(res * f32(1000.0)) / f32(1000.0))   # DSSP compatibility mode
+                if res < f32(-9.9):
+                    res = f32(-9.9)
+            if res < en[donor][0]:
+                acc[donor][1], en[donor][1] = acc[donor][0], en[donor][0]
+                acc[donor][0], en[donor][0] = acceptor, res
+            elif res < en[donor][1]:
+                acc[donor][1], en[donor][1] = acceptor, res
+
+        for i in range(R - 1):
+            for j in range(i + 1, R):
+                if dist(CA[i], CA[j]) < f32(9.0):
+                    energy(i, j)
+                    if j != i + 1:
+                        energy(j, i)
+
+        def bond(d, a):
+            return (acc[d][0] == a and en[d][0] < f32(-0.5)) or (acc[d][1] == a and en[d][1] < f32(-0.5))
+
+        ss = [0] * R
+        ladders = []   # [i_first, i_last, j_first, j_last, type, alive]
+        for i in range(1, R - 4):
+            for j in range(i + 3, R - 1):
+                typ = 0
+                if no_break(i - 1, i + 1) and no_break(j - 1, j + 1):
+                    if (bond(i + 1, j) and bond(j, i - 1)) or (bond(j + 1, i) and bond(i, j - 1)):
+                        typ = 1
+                    elif (bond(i + 1, j - 1) and bond(j + 1, i - 1)) or (bond(j, i) and bond(i, j)):
+                        typ = 2
+                if not typ:
+                    continue
+                for lad in ladders:
+                    if lad[4] != typ or i != lad[1] + 1:
+                        continue
+                    if typ == 1 and lad[3] + 1 == j:
+                        lad[1], lad[3] = i, j
+                        break
+                    if typ == 2 and lad[2] - 1 == j:
+                        lad[1], lad[2] = i, j
+                        break
+                else:
+                    ladders.append([i, i, j, j, typ, 1])
+        for a in range(len(ladders)):
+            if not ladders[a][5]:
+                continue
+            for b in range(a + 1, len(ladders)):
+                if not ladders[b][5]:
+                    continue
+                ibi, iei, jbi, jei = ladders[a][:4]
+                ibj, iej, jbj, jej = ladders[b][:4]
+                if (ladders[a][4] != ladders[b][4] or not no_break(min(ibi, ibj), max(iei, iej))
+                        or not no_break(min(jbi, jbj), max(jei, jej)) or ibj - iei >= 6 or (iei >= ibj and ibi <= iej)):
+                    continue
+                if ladders[a][4] == 1:
+                    bulge = (jbj - jei < 6 and ibj - iei < 3) or (jbj - jei < 3)
+                else:
+                    bulge = (jbi - jej < 6 and ibj - iei < 3) or (jbi - jej < 3)
+                if bulge:
+                    ladders[a][0], ladders[a][1] = min(ibi, ibj), max(iei, iej)
+                    ladders[a][2], ladders[a][3] = min(jbi, jbj), max(jei, jej)
+                    ladders[b][5] = 0
+        for lad in ladders:
+            if not lad[5]:
+                continue
+            code = 3 if (lad[1] - lad[0] >= 1 or lad[3] - lad[2] >= 1) else 2
+            for r in list(range(lad[0], lad[1] + 1)) + list(range(lad[2], lad[3] + 1)):
+                if ss[r] != 3:
+                    ss[r] = code
+        NONE, START, END, BOTH, MID = 0, 1, 2, 3, 4
+        hf = [[NONE] * R for _ in range(3)]
+        for s in range(3):
+            stride = s + 3
+            for i in range(R - stride):
+                if no_break(i, i + stride) and bond(i + stride, i):
+                    hf[s][i + stride] = BOTH if hf[s][i + stride] == START else END
+                    for j in range(i + 1, i + stride):
+                        if hf[s][j] == NONE:
+                            hf[s][j] = MID
+                    hf[s][i] = BOTH if hf[s][i] == END else START
+        bend = [False] * R
+        for i in range(2, R - 2):
+            if not no_break(i - 2, i + 2):
+                continue
+            u, v = CA[i] - CA[i - 2], CA[i + 2] - CA[i]
+            ck = ((u[0] * v[0] + u[1] * v[1]) + u[2] * v[2]) / (np.sqrt((u[0] * u[0] + u[1] * u[1]) + u[2] * u[2])
+                                                               * np.sqrt((v[0] * v[0] + v[1] * v[1]) + v[2] * v[2]))
+            kappa = np.arccos(np.clip(f32(ck), f32(-1.0), f32(1.0))) * f32(57.29577951308232)
+            bend[i] = bool(kappa > f32(70.0))
+
+        def start(r, s):
+            return hf[s][r] in (START, BOTH)
+
+        for i in range(1, R - 4):
+            if start(i, 1) and start(i - 1, 1):
+                for j in range(i, i + 4):
+                    ss[j] = 1
+        for i in range(1, R - 3):
+            if start(i, 0) and start(i - 1, 0) and all(ss[j] in (0, 4) for j in range(i, i + 3)):
+                for j in range(i, i + 3):
+                    ss[j] = 4
+        for i in range(1, R - 5):
+            if start(i, 2) and start(i - 1, 2) and all(ss[j] in (0, 5) for j in range(i, i + 5)):
+                for j in range(i, i + 5):
+                    ss[j] = 5
+        for i in range(1, R - 1):
+            if ss[i] != 0:
+                continue
+            turn = any(i >= k and start(i - k, s) for s in range(3) for k in range(1, s + 3))
+            if turn:
+                ss[i] = 6
+            elif bend[i]:
+                ss[i] = 7
+        out[t] = ss
+    return out
+
+
+def _roundf(x):
+    """C roundf: half away from zero, float32."""
+    x = np.float32(x)
+    return np.float32(np.sign(x) * np.floor(np.abs(x) + np.float32(0.5)))

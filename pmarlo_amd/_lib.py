@@ -56,6 +56,9 @@ _PROTOTYPES: dict[str, tuple] = {
     "msm_featurize_rg": (_i32, [_vp, _vp, _i64, _i32, _vp, _i64, _i32]),
     "msm_featurize_angles": (_i32, [_vp, _vp, _i64, _i32, _vp, _i32, _vp, _i64, _i32]),
     "msm_featurize_dihedrals": (_i32, [_vp, _vp, _i64, _i32, _vp, _i32, _i32, _vp, _i64, _i32]),
+    "msm_featurize_sasa": (_i32, [_vp, _vp, _i64, _i32, _vp, _vp, _i32, _vp]),
+    "msm_hbond_presence": (_i32, [_vp, _vp, _i64, _i32, _vp, _i32, C.c_float, C.c_float, _vp]),
+    "msm_dssp": (_i32, [_vp, _vp, _i64, _i32, _vp, _vp, _vp, _i32, _vp]),
     "msm_count_transitions": (_i32, [_vp, _vp, _i64, _vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp]),
     "msm_count_transitions_weighted": (
         _i32, [_vp, _vp, _vp, _i64, _vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp]),

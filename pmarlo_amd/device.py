@@ -228,6 +228,47 @@ class Engine:
         self.sync()
         return out
 
+    def featurize_sasa(self, xyz: DeviceArray, radii, points) -> DeviceArray:
+        """Shrake-Rupley accessible area per atom: float32 [n, A] (nm^2).  `radii` float32 [A] already include the
+        probe radius, `points` float32 [P, 3] are the unit sphere points."""
+        n, A, _ = xyz.shape
+        r = self.to_device(np.ascontiguousarray(radii, np.float32).reshape(A))
+        pts = np.ascontiguousarray(points, np.float32).reshape(-1, 3)
+        p = self.to_device(pts)
+        out = self.empty((n, A), np.float32)
+        check(lib.msm_featurize_sasa(self.handle, xyz.ptr, n, A, r.ptr, p.ptr, pts.shape[0], out.ptr), self.handle)
+        return out
+
+    def hbond_presence(self, xyz: DeviceArray, triplets, dist_cutoff: float, angle_cutoff: float) -> np.ndarray:
+        """Frames in which each (donor, hydrogen, acceptor) triplet meets the Baker-Hubbard criteria: int64 [Tn]."""
+        n, A, _ = xyz.shape
+        tr = np.ascontiguousarray(triplets, np.int32).reshape(-1, 3)
+        if tr.size and (tr.min() < 0 or tr.max() >= A):
+            raise ValueError(f"atom index out of range [0, {A})")
+        if tr.shape[0] == 0:
+            return np.zeros((0,), np.int64)
+        td = self.to_device(tr)
+        counts = self.empty((tr.shape[0],), np.uint64)
+        check(lib.msm_hbond_presence(self.handle, xyz.ptr, n, A, td.ptr, tr.shape[0], float(dist_cutoff),
+                                     float(angle_cutoff), counts.ptr), self.handle)
+        return counts.to_host().astype(np.int64)
+
+    def dssp(self, xyz: DeviceArray, backbone, chain, proline) -> np.ndarray:
+        """Kabsch-Sander codes per frame and protein residue: uint8 [n, R] (0 loop, 1 H, 2 B, 3 E, 4 G, 5 I, 6 T, 7 S)."""
+        n, A, _ = xyz.shape
+        bb = np.ascontiguousarray(backbone, np.int32).reshape(-1, 4)
+        R = bb.shape[0]
+        if R == 0 or n == 0:
+            return np.zeros((n, R), np.uint8)
+        if bb.min() < 0 or bb.max() >= A:
+            raise ValueError(f"atom index out of range [0, {A})")
+        bd = self.to_device(bb)
+        cd = self.to_device(np.ascontiguousarray(chain, np.int32).reshape(R))
+        pd_ = self.to_device(np.ascontiguousarray(proline, np.uint8).reshape(R))
+        codes = self.empty((n, R), np.uint8)
+        check(lib.msm_dssp(self.handle, xyz.ptr, n, A, bd.ptr, cd.ptr, pd_.ptr, R, codes.ptr), self.handle)
+        return codes.to_host()
+
     def featurize(self, xyz: DeviceArray, *, pairs=None, triplets=None, quads=None, dihedral_mode: int = 0,
                   out: DeviceArray | None = None) -> DeviceArray:
         """xyz float32 [n, A, 3] -> float32 [n, F]: distance columns, then angle columns, then

@@ -40,6 +40,12 @@ def parse_feature_spec(spec: str) -> Tuple[str, Dict[str, Any]]:
     """``"distance([0, 5])"`` -> ("distance", {"indices": [0, 5]}); ``"phi_psi"`` -> ("phi_psi", {})."""
     s = spec.strip()
     if "(" not in s:
+        if ":" in s:   # namespaced forms of the structure features (S/features/base.py:160-165)
+            prefix = s.split(":", 1)[0].strip().lower()
+            alias = {"sasa": "sasa", "hbonds": "hbonds_count", "hbond": "hbonds_count",
+                     "hbondscount": "hbonds_count", "ssfrac": "ssfrac", "secondary": "ssfrac"}.get(prefix)
+            if alias:
+                return alias, {}
         return s, {}
     name, rest = s.split("(", 1)
     body = rest.rsplit(")", 1)[0].strip()

@@ -12,7 +12,8 @@ from ..device import get_engine
 from .base import register_feature
 
 __all__ = ["PhiPsiFeature", "Chi1Feature", "DistanceFeature", "AngleFeature", "DihedralFeature",
-           "RadiusOfGyrationFeature", "DistancePairFeature", "ContactsPairFeature"]
+           "RadiusOfGyrationFeature", "DistancePairFeature", "ContactsPairFeature", "SASAFeature",
+           "HBondsCountFeature", "SecondaryStructureFractionFeature"]
 
 
 def _device_features(traj, **kw) -> np.ndarray:
@@ -166,6 +167,85 @@ class ContactsPairFeature(_PairKwFeature):
         return out.to_host().astype(float)
 
 
+class SASAFeature:
+    """``sasa``: total Shrake-Rupley solvent accessible surface per frame, the sum of the per-residue areas
+    (S/features/builtins.py:171-188).  Like the reference, any failure of the computation (an element without a
+    radius, ...) yields a column of zeros."""
+
+    name = "sasa"
+
+    def __init__(self) -> None:
+        self._periodic = np.array([False], dtype=bool)
+        self.labels: list[str] | None = None
+
+    def compute(self, traj, **kwargs) -> np.ndarray:
+        self.labels = ["sasa"]
+        try:
+            from .structure import shrake_rupley
+
+            sasa = shrake_rupley(traj, mode="residue")  # (n_frames, n_residues)
+            return np.sum(sasa, axis=1, keepdims=True).astype(float)
+        except (ValueError, KeyError, IndexError):
+            return np.zeros((traj.n_frames, 1), dtype=float)
+
+    def is_periodic(self) -> np.ndarray:
+        return self._periodic
+
+
+class HBondsCountFeature:
+    """``hbonds_count``: the number of Baker-Hubbard hydrogen bonds of the TRAJECTORY (present in more than 10 % of
+    its frames), repeated for every frame -- the reference's "static count" (S/features/builtins.py:194-213)."""
+
+    name = "hbonds_count"
+
+    def __init__(self) -> None:
+        self._periodic = np.array([False], dtype=bool)
+        self.labels: list[str] | None = None
+
+    def compute(self, traj, **kwargs) -> np.ndarray:
+        self.labels = ["hbonds_count"]
+        try:
+            from .structure import baker_hubbard
+
+            hbonds = baker_hubbard(traj, periodic=True)
+            return np.full((traj.n_frames, 1), float(len(hbonds)), dtype=float)
+        except (ValueError, KeyError, IndexError):
+            return np.zeros((traj.n_frames, 1), dtype=float)
+
+    def is_periodic(self) -> np.ndarray:
+        return self._periodic
+
+
+class SecondaryStructureFractionFeature:
+    """``ssfrac``: fractions of helix (H, G, I), sheet (E, B) and coil residues per frame from the DSSP codes
+    (S/features/builtins.py:219-246); 'NA' residues count in the denominator, as in the reference."""
+
+    name = "ssfrac"
+
+    def __init__(self) -> None:
+        self._periodic = np.array([False, False, False], dtype=bool)
+        self.labels: list[str] | None = None
+
+    def compute(self, traj, **kwargs) -> np.ndarray:
+        self.labels = ["ssfrac:helix", "ssfrac:sheet", "ssfrac:coil"]
+        try:
+            from .structure import compute_dssp
+
+            dssp = compute_dssp(traj)  # (n_frames, n_residues) of 'H' / 'E' / 'C' / 'NA'
+            n = float(dssp.shape[1]) if dssp.shape[1] > 0 else 1.0
+            # the reference counts per row with float division, then coil = 1 - helix - sheet clipped at 0
+            helix = np.isin(dssp, ["H", "G", "I"]).sum(axis=1) / n
+            sheet = np.isin(dssp, ["E", "B"]).sum(axis=1) / n
+            coil = np.maximum(0.0, 1.0 - helix - sheet)
+            return np.stack([helix, sheet, coil], axis=1).astype(float)
+        except (ValueError, KeyError, IndexError):
+            return np.zeros((traj.n_frames, 3), dtype=float)
+
+    def is_periodic(self) -> np.ndarray:
+        return self._periodic
+
+
 for _cls in (PhiPsiFeature, Chi1Feature, DistanceFeature, AngleFeature, DihedralFeature, RadiusOfGyrationFeature,
-             DistancePairFeature, ContactsPairFeature):
+             DistancePairFeature, ContactsPairFeature, SASAFeature, HBondsCountFeature,
+             SecondaryStructureFractionFeature):
     register_feature(_cls())
