@@ -399,6 +399,16 @@ msm_status msm_kmeans_accumulate_packed(msm_ctx* ctx, const void* d_x, msm_dtype
                                         int64_t ld, const double* d_centers, int k, const double* d_mean,
                                         const double* d_std, const void* d_image, const double* d_state,
                                         int64_t* d_sums, int64_t* d_counts);
+/* Incremental form of the accumulate pass: d_prev_labels int32 [n] holds the centre each frame is booked under
+ * (-1: none yet) and is updated in place; a frame whose centre did not change is left alone, one that moved is
+ * subtracted from its old centre's sums / count and added to the new one's.  d_sums / d_counts must therefore
+ * PERSIST between calls (msm_kmeans_update with clear = 0).  The sums are 64-bit fixed-point integers, so they hold
+ * the bits of a full re-accumulation; after the first passes of a Lloyd run only a few per cent of the frames move.
+ * d_image may be NULL. */
+msm_status msm_kmeans_accumulate_delta(msm_ctx* ctx, const void* d_x, msm_dtype dtype, int64_t n, int d,
+                                       int64_t ld, const double* d_centers, int k, const double* d_mean,
+                                       const double* d_std, const void* d_image, const double* d_state,
+                                       int32_t* d_prev_labels, int64_t* d_sums, int64_t* d_counts);
 msm_status msm_kmeans_filter_scanned(msm_ctx* ctx, uint64_t* h_out, int reset);
 
 /* d_out[0] = sum of d_v[0..n) with a fixed-order two-level reduction (inertia =

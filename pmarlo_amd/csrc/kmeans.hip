@@ -702,13 +702,28 @@ __global__ __launch_bounds__(kMT, kMT == 1024 ? 4 : 2) void kmeans_mfma_kernel(
         for (int u = 0; u < NF; ++u) {
             if (!fok[u]) continue;
             if constexpr (ACCUM) {
-                unsigned long long* srow = (lds_acc ? lsum : sums) + (size_t)bidx[u] * d;
+                // delta mode (labels != NULL): only frames that changed centre since the last pass move their
+                // contribution (kmeans_filter.h has the same rule); the four g lanes of a frame read the old label
+                // before lane g == 0 replaces it
+                const int old = labels ? labels[fidx[u]] : -1;
+                if (!labels || old != bidx[u]) {
+                    unsigned long long* base = lds_acc ? lsum : sums;
+                    unsigned long long* srow = base + (size_t)bidx[u] * d;
 #pragma unroll
-                for (int s = 0; s < KS; ++s) {
-                    const int f = 4 * s + g;
-                    if (f < d) atomicAdd(&srow[f], (unsigned long long)to_fixed(zb[u][s], scale));
+                    for (int s = 0; s < KS; ++s) {
+                        const int f = 4 * s + g;
+                        if (f < d) {
+                            const unsigned long long fx = (unsigned long long)to_fixed(zb[u][s], scale);
+                            atomicAdd(&srow[f], fx);
+                            if (old >= 0) atomicAdd(&base[(size_t)old * d + f], 0ull - fx);
+                        }
+                    }
+                    if (g == 0) {
+                        atomicAdd((lds_acc ? lcnt : counts) + bidx[u], 1ull);
+                        if (old >= 0) atomicAdd((lds_acc ? lcnt : counts) + old, ~0ull);
+                        if (labels) labels[fidx[u]] = bidx[u];
+                    }
                 }
-                if (g == 0) atomicAdd((lds_acc ? lcnt : counts) + bidx[u], 1ull);
             } else {
                 if (g == 0) {
                     labels[fidx[u]] = bidx[u];
@@ -1038,7 +1053,8 @@ msm_status msm_kmeans_fit_begin(msm_ctx* ctx, const void* d_x, msm_dtype dtype, 
 
 static msm_status kmeans_accumulate_impl(msm_ctx* ctx, const void* d_x, msm_dtype dtype, int64_t n, int d, int64_t ld,
                                          const double* d_centers, int k, const double* d_mean, const double* d_std,
-                                         const void* d_image, const double* d_state, int64_t* d_sums, int64_t* d_counts) {
+                                         const void* d_image, const double* d_state, int64_t* d_sums, int64_t* d_counts,
+                                         int32_t* d_prev_labels = nullptr) {
     if (!ctx) return MSM_ERR_INVALID;
     MSM_REQUIRE(ctx, n >= 0 && d >= 1 && k >= 1 && ld >= d, "msm_kmeans_accumulate: bad shape");
     MSM_REQUIRE(ctx, (d_mean == nullptr) == (d_std == nullptr), "msm_kmeans_accumulate: mean/std must come together");
@@ -1046,12 +1062,22 @@ static msm_status kmeans_accumulate_impl(msm_ctx* ctx, const void* d_x, msm_dtyp
     if (n == 0) return MSM_OK;
     MSM_REQUIRE(ctx, d_x && d_centers && d_state && d_sums && d_counts, "msm_kmeans_accumulate: NULL pointer");
     if (dtype == MSM_F32)
-        return dispatch_mfma<float, true>(ctx, (const float*)d_x, n, d, ld, d_centers, k, d_mean, d_std, nullptr,
+        return dispatch_mfma<float, true>(ctx, (const float*)d_x, n, d, ld, d_centers, k, d_mean, d_std, d_prev_labels,
                                           nullptr, (const FitState*)d_state, (unsigned long long*)d_sums,
                                           (unsigned long long*)d_counts, d_image);
-    return dispatch_mfma<double, true>(ctx, (const double*)d_x, n, d, ld, d_centers, k, d_mean, d_std, nullptr, nullptr,
-                                       (const FitState*)d_state, (unsigned long long*)d_sums,
+    return dispatch_mfma<double, true>(ctx, (const double*)d_x, n, d, ld, d_centers, k, d_mean, d_std, d_prev_labels,
+                                       nullptr, (const FitState*)d_state, (unsigned long long*)d_sums,
                                        (unsigned long long*)d_counts, d_image);
+}
+
+msm_status msm_kmeans_accumulate_delta(msm_ctx* ctx, const void* d_x, msm_dtype dtype, int64_t n, int d, int64_t ld,
+                                       const double* d_centers, int k, const double* d_mean, const double* d_std,
+                                       const void* d_image, const double* d_state, int32_t* d_prev_labels,
+                                       int64_t* d_sums, int64_t* d_counts) {
+    if (!ctx) return MSM_ERR_INVALID;
+    MSM_REQUIRE(ctx, d_prev_labels || n == 0, "msm_kmeans_accumulate_delta: NULL label buffer");
+    return kmeans_accumulate_impl(ctx, d_x, dtype, n, d, ld, d_centers, k, d_mean, d_std, d_image, d_state, d_sums,
+                                  d_counts, d_prev_labels);
 }
 
 msm_status msm_kmeans_accumulate(msm_ctx* ctx, const void* d_x, msm_dtype dtype, int64_t n, int d, int64_t ld,
@@ -1088,12 +1114,16 @@ msm_status msm_kmeans_fit(msm_ctx* ctx, const void* d_x, msm_dtype dtype, int64_
     msm_status rs = msm_kmeans_fit_begin(ctx, d_x, dtype, n, d, ld, d_mean, d_std, k, seed, init_centers, (double)n,
                                          tol2, d_centers, d_state, 0);
     if (rs != MSM_OK) return rs;
-    const size_t acc_bytes = (size_t)k * (d + 1) * sizeof(unsigned long long);
-    rs = msm_reserve_scratch(ctx, acc_bytes);
+    const size_t acc_bytes = ((size_t)k * (d + 1) * sizeof(unsigned long long) + 15) & ~(size_t)15;
+    rs = msm_reserve_scratch(ctx, acc_bytes + (size_t)n * sizeof(int32_t));
     if (rs != MSM_OK) return rs;
     int64_t* sums = (int64_t*)ctx->scratch;
     int64_t* counts = sums + (size_t)k * d;
+    // the member sums persist over the iterations and follow the frames that change centre (integer sums: the
+    // bits of a full re-accumulation); prev = the centre each frame is booked under, -1 before the first pass
+    int32_t* prev = (int32_t*)((char*)ctx->scratch + acc_bytes);
     MSM_HIP(ctx, hipMemsetAsync(sums, 0, acc_bytes, ctx->stream));
+    MSM_HIP(ctx, hipMemsetAsync(prev, 0xFF, (size_t)n * sizeof(int32_t), ctx->stream));
     // the frames' bf16 images are built once and serve every iteration (kmeans_filter.h)
     const void* image = nullptr;
     if (max_iter > 0 && filter_fits(k, d, true)) {
@@ -1104,9 +1134,10 @@ msm_status msm_kmeans_fit(msm_ctx* ctx, const void* d_x, msm_dtype dtype, int64_
         image = ctx->km_image;
     }
     for (int it = 0; it < max_iter; ++it) {
-        rs = kmeans_accumulate_impl(ctx, d_x, dtype, n, d, ld, d_centers, k, d_mean, d_std, image, d_state, sums, counts);
+        rs = kmeans_accumulate_impl(ctx, d_x, dtype, n, d, ld, d_centers, k, d_mean, d_std, image, d_state, sums, counts,
+                                    prev);
         if (rs != MSM_OK) return rs;
-        rs = msm_kmeans_update(ctx, sums, counts, k, d, d_centers, d_state, 1);
+        rs = msm_kmeans_update(ctx, sums, counts, k, d, d_centers, d_state, 0);
         if (rs != MSM_OK) return rs;
     }
     return MSM_OK;

@@ -168,16 +168,15 @@ struct FilterShape {
     static constexpr int kTileBytes = NM * 1024 + 16 * D1 * 8;    // image + table rows of one 16-centre tile
 };
 
+// One wave stages one 16-centre tile (simg: NM * 64 * 8 shorts of LDS of its own).  `centers` may be global or LDS.
 template <int NM>
-__global__ __launch_bounds__(64) void kmeans_filter_stage_kernel(const double* __restrict__ centers, int k, int d,
-                                                                uint4* __restrict__ img_g, double* __restrict__ cs_g,
-                                                                int* __restrict__ flag) {
+__device__ __forceinline__ void filter_stage_tile(int tile, int lane, unsigned short* simg, const double* centers, int k,
+                                                  int d, uint4* __restrict__ img_g, double* __restrict__ cs_g,
+                                                  int* __restrict__ flag) {
     using S = FilterShape<NM>;
     constexpr double kappa = filter_kappa(NM);
-    __shared__ unsigned short simg[NM * 64 * 8];
-    const int tile = blockIdx.x, lane = threadIdx.x;
     for (int i = lane; i < NM * 64 * 4; i += 64) reinterpret_cast<unsigned*>(simg)[i] = 0u;
-    __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");   // one wave, LDS in order: only the compiler must not reorder
     auto slot_addr = [&](int i, int sl) {      // bf16 element of tile row i, slot sl
         const int m = sl >> 5, qq = (sl & 31) >> 3, e = sl & 7;
         return ((m * 64) + qq * 16 + i) * 8 + e;
@@ -222,10 +221,18 @@ __global__ __launch_bounds__(64) void kmeans_filter_stage_kernel(const double* _
             for (int t = 0; t < 6; ++t) simg[slot_addr(r, t * d + f)] = (unsigned short)cp[filter_part_c(t)];
         }
     }
-    __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     for (int i = lane; i < NM * 64; i += 64) img_g[(size_t)tile * NM * 64 + i] = reinterpret_cast<const uint4*>(simg)[i];
-    const bool any_bad = __any(bad_row != 0);      // one wave per tile: every launch rewrites its flag
+    const bool any_bad = __any(bad_row != 0);      // every launch rewrites its flag
     if (lane == 0) flag[tile] = any_bad ? 1 : 0;
+}
+
+template <int NM>
+__global__ __launch_bounds__(64) void kmeans_filter_stage_kernel(const double* __restrict__ centers, int k, int d,
+                                                                uint4* __restrict__ img_g, double* __restrict__ cs_g,
+                                                                int* __restrict__ flag) {
+    __shared__ __attribute__((aligned(16))) unsigned short simg[NM * 64 * 8];
+    filter_stage_tile<NM>(blockIdx.x, threadIdx.x, simg, centers, k, d, img_g, cs_g, flag);
 }
 
 // cross-row butterflies over the 4 lanes (j, j + 16, j + 32, j + 48) that share a frame: v_permlane16_swap /
@@ -476,19 +483,34 @@ __global__ __launch_bounds__(1024, 4) void kmeans_filter_kernel(
             KSTAMP(4);
             if (fok && certified) {
                 if constexpr (ACCUM) {
-                    // lane q adds features q, q + 4, q + 8
+                    // delta mode (labels != NULL): the sums follow the frames that CHANGED centre since the last pass
+                    // (integer sums: the same bits as a full re-accumulation); else every frame is added
+                    const int old = labels ? labels[f0] : -1;
+                    if (!labels || old != bi) {
+                        // lane q adds features q, q + 4, q + 8
 #pragma unroll
-                    for (int i = 0; i < (DP + 3) / 4; ++i) {
-                        double v = z[4 * i];
-                        if (4 * i + 1 < DP) v = q == 1 ? z[4 * i + 1] : v;
-                        if (4 * i + 2 < DP) v = q == 2 ? z[4 * i + 2] : v;
-                        if (4 * i + 3 < DP) v = q == 3 ? z[4 * i + 3] : v;
-                        const int f = 4 * i + q;
-                        if (f < d) atomicAdd(&lsum[(size_t)bi * d + f], (unsigned long long)to_fixed(v, scale));
+                        for (int i = 0; i < (DP + 3) / 4; ++i) {
+                            double v = z[4 * i];
+                            if (4 * i + 1 < DP) v = q == 1 ? z[4 * i + 1] : v;
+                            if (4 * i + 2 < DP) v = q == 2 ? z[4 * i + 2] : v;
+                            if (4 * i + 3 < DP) v = q == 3 ? z[4 * i + 3] : v;
+                            const int f = 4 * i + q;
+                            if (f < d) {
+                                const unsigned long long fx = (unsigned long long)to_fixed(v, scale);
+                                atomicAdd(&lsum[(size_t)bi * d + f], fx);
+                                if (old >= 0) atomicAdd(&lsum[(size_t)old * d + f], 0ull - fx);
+                            }
+                        }
+                        if (q == 0) {
+                            atomicAdd(&lcnt[bi], 1ull);
+                            if (old >= 0) atomicAdd(&lcnt[old], ~0ull);
+                        }
                     }
-                    if (q == 0) atomicAdd(&lcnt[bi], 1ull);
                 } else {
                     if (q == 0) write_label(f0, bi, best, z);
+                }
+                if constexpr (ACCUM) {
+                    if (labels && q == 0) labels[f0] = bi;
                 }
             }
             KSTAMP(5);
@@ -513,11 +535,22 @@ __global__ __launch_bounds__(1024, 4) void kmeans_filter_kernel(
                 }
                 if (sbi >= k) { sbi = 0; sbest = -__builtin_inf(); }   // every score NaN: label 0, as the fp64 kernel
                 if constexpr (ACCUM) {
-                    double v = zz[0];                                   // lane f adds feature f
+                    const int old = labels ? labels[t] : -1;
+                    if (!labels || old != sbi) {
+                        double v = zz[0];                                   // lane f adds feature f
 #pragma unroll
-                    for (int f = 1; f < DP; ++f) v = lane == f ? zz[f] : v;
-                    if (lane < d) atomicAdd(&lsum[(size_t)sbi * d + lane], (unsigned long long)to_fixed(v, scale));
-                    if (lane == 0) atomicAdd(&lcnt[sbi], 1ull);
+                        for (int f = 1; f < DP; ++f) v = lane == f ? zz[f] : v;
+                        if (lane < d) {
+                            const unsigned long long fx = (unsigned long long)to_fixed(v, scale);
+                            atomicAdd(&lsum[(size_t)sbi * d + lane], fx);
+                            if (old >= 0) atomicAdd(&lsum[(size_t)old * d + lane], 0ull - fx);
+                        }
+                        if (lane == 0) {
+                            atomicAdd(&lcnt[sbi], 1ull);
+                            if (old >= 0) atomicAdd(&lcnt[old], ~0ull);
+                            if (labels) labels[t] = sbi;
+                        }
+                    }
                 } else {
                     if (lane == 0) write_label(t, sbi, sbest, zz);
                 }

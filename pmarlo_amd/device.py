@@ -92,6 +92,11 @@ class DeviceArray:
         check(lib.msm_memset(self.engine.handle, self.ptr, 0, self.nbytes), self.engine.handle)
         return self
 
+    def fill_bytes_(self, byte: int) -> "DeviceArray":
+        """Every byte set to `byte` (0xFF makes int32 / int64 entries -1)."""
+        check(lib.msm_memset(self.engine.handle, self.ptr, int(byte) & 0xFF, self.nbytes), self.engine.handle)
+        return self
+
     def view(self, shape, dtype=None, offset_elems: int = 0) -> "DeviceArray":
         dtype = self.dtype if dtype is None else np.dtype(dtype)
         v = DeviceArray(self.engine, self.ptr + offset_elems * self.dtype.itemsize, shape, dtype, False)
@@ -537,9 +542,19 @@ class Engine:
 
     def kmeans_accumulate(self, x: DeviceArray, centers: DeviceArray, state: DeviceArray, sums: DeviceArray,
                           counts: DeviceArray, *, mean: DeviceArray | None = None, std: DeviceArray | None = None,
-                          image: DeviceArray | None = None):
+                          image: DeviceArray | None = None, prev_labels: DeviceArray | None = None):
+        """Member sums / counts of one Lloyd pass.  With `prev_labels` (int32 [n], -1 before the first pass, updated
+        in place) only the frames that changed centre move their contribution: `sums` / `counts` must then persist
+        between the passes (kmeans_update(clear=False))."""
         n, d = x.shape
         k = centers.shape[0]
+        if prev_labels is not None:
+            check(lib.msm_kmeans_accumulate_delta(self.handle, x.ptr, _dtype_code(x.dtype), n, d, d, centers.ptr, k,
+                                                  mean.ptr if mean is not None else None,
+                                                  std.ptr if std is not None else None,
+                                                  image.ptr if image is not None else None, state.ptr,
+                                                  prev_labels.ptr, sums.ptr, counts.ptr), self.handle)
+            return
         check(lib.msm_kmeans_accumulate_packed(self.handle, x.ptr, _dtype_code(x.dtype), n, d, d, centers.ptr, k,
                                                mean.ptr if mean is not None else None,
                                                std.ptr if std is not None else None,

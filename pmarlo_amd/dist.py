@@ -295,6 +295,12 @@ class ShardedMSM:
         self.diag = eng.empty((1,), np.float64)
         self.km_sums = b["km_acc"].view((k * d,), np.int64)
         self.km_counts = b["km_acc"].view((k,), np.int64, offset_elems=k * d)
+        # The member sums of the Lloyd passes are incremental: they persist over the iterations and only the frames
+        # that changed centre move their contribution (64-bit fixed-point integers: the bits of a full
+        # re-accumulation; after two passes < 10 % of the frames move).  With several shards the persistent copy is
+        # local and the exchange buffer receives a fresh copy of it before every all-reduce.
+        multi_shard = self.comm is not None and (self.comm.world > 1 or self.always_exchange)
+        self.km_local = eng.empty((k * d + k,), np.int64) if multi_shard else None
         # bf16 frame images of the k-means filter: built once per step after the projection, read by all Lloyd
         # passes and the final assignment (None when d / k are outside the filter's range)
         nbytes = eng.kmeans_image_bytes(n, d)
@@ -358,21 +364,25 @@ class ShardedMSM:
             comm.broadcast("centers", 0)
             comm.allreduce_min("fit_scale")
             comm.reciprocal("fit_inv_scale", "fit_scale")   # 2^-e: exact, no second collective
-        b["km_acc"].zero_()
+        acc = self.km_local if self.km_local is not None else b["km_acc"]
+        acc.zero_()
+        acc_sums, acc_counts = acc.view((k * d,), np.int64), acc.view((k,), np.int64, offset_elems=k * d)
+        self.labels.fill_bytes_(0xFF)          # the centre each frame is booked under: none yet
         if self.km_image is not None:
             eng.kmeans_pack(self.Y, image=self.km_image)
         for _ in range(cfg.kmeans_iters):
             if self.time_accum:
                 e0, e1 = eng.event(), eng.event()
                 e0.record()
-            eng.kmeans_accumulate(self.Y, b["centers"], b["fit_state"], self.km_sums, self.km_counts,
-                                  image=self.km_image)
+            eng.kmeans_accumulate(self.Y, b["centers"], b["fit_state"], acc_sums, acc_counts,
+                                  image=self.km_image, prev_labels=self.labels)
             if self.time_accum:
                 e1.record()
                 self.accum_events.append((e0, e1))
             if multi:
+                b["km_acc"].copy_from(self.km_local)
                 comm.allreduce_sum("km_acc")
-            eng.kmeans_update(self.km_sums, self.km_counts, b["centers"], b["fit_state"], clear=True)
+            eng.kmeans_update(self.km_sums, self.km_counts, b["centers"], b["fit_state"], clear=False)
         eng.kmeans_assign(self.Y, b["centers"], labels=self.labels, image=self.km_image)
         self._stamp("kmeans")
         # 5. lag-tau counts (a whole lag scan in one pass and ONE collective) + row-normalised transition matrix

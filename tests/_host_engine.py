@@ -35,6 +35,14 @@ class HostArray:
         self.a[...] = 0
         return self
 
+    def fill_bytes_(self, byte: int):
+        self.a.view(np.uint8)[...] = int(byte) & 0xFF
+        return self
+
+    def copy_from(self, src):
+        self.a.reshape(-1).view(np.uint8)[...] = src.a.reshape(-1).view(np.uint8)
+        return self
+
     def view(self, shape, dtype=None, offset_elems: int = 0):
         flat = self.a.reshape(-1)
         dtype = self.a.dtype if dtype is None else np.dtype(dtype)
@@ -133,14 +141,27 @@ class HostEngine:
             centers.a[j] = Y[t]
         return centers, state
 
-    def kmeans_accumulate(self, x, centers, state, sums, counts, **_):
+    def kmeans_accumulate(self, x, centers, state, sums, counts, prev_labels=None, **_):
         if state.a[5] != 0.0:
             return
         Y = x.a.astype(np.float64)
         lab = cport.kmeans_assign(Y, centers.a)
         k, d = centers.shape
-        np.add.at(sums.a.reshape(k, d), lab, np.rint(Y * state.a[0]).astype(np.int64))
-        counts.a += np.bincount(lab, minlength=k).astype(np.int64)
+        fixed = np.rint(Y * state.a[0]).astype(np.int64)
+        if prev_labels is None:
+            np.add.at(sums.a.reshape(k, d), lab, fixed)
+            counts.a += np.bincount(lab, minlength=k).astype(np.int64)
+            return
+        # incremental form (msm_kmeans_accumulate_delta): only the frames that changed centre move
+        old = prev_labels.a
+        moved = np.nonzero(old != lab)[0]
+        S = sums.a.reshape(k, d)
+        np.add.at(S, lab[moved], fixed[moved])
+        np.add.at(counts.a, lab[moved], 1)
+        had = moved[old[moved] >= 0]
+        np.subtract.at(S, old[had], fixed[had])
+        np.subtract.at(counts.a, old[had], 1)
+        old[...] = lab
 
     def kmeans_update(self, sums, counts, centers, state, clear=True):
         if state.a[5] != 0.0:

@@ -173,3 +173,28 @@ def test_project_hands_absmax_to_fit_begin(engine):
         c2, s2 = engine.kmeans_fit_begin(Y, 5, seed=1, n_total=n, tol2=0.0)
         np.testing.assert_array_equal(s1.to_host(), s2.to_host())
         np.testing.assert_array_equal(c1.to_host(), c2.to_host())
+
+
+@pytest.mark.parametrize("d,k", [(10, 300), (24, 60)])       # bf16-filter shape, all-fp64 shape
+def test_incremental_member_sums_equal_full_passes(engine, d, k):
+    """msm_kmeans_accumulate_delta: sums that follow only the frames that changed centre hold, pass after pass, the
+    bits of a full re-accumulation (64-bit fixed-point integers), and the label buffer holds the current assignment."""
+    n = 60_000
+    X = _gen.correlated_series(n, d, seed=3).astype(np.float64)
+    xd = engine.to_device(X)
+    centers, state = engine.kmeans_fit(xd, k, seed=5, max_iter=0)
+    sums_i, counts_i = engine.zeros((k * d,), np.int64), engine.zeros((k,), np.int64)
+    prev = engine.empty((n,), np.int32).fill_bytes_(0xFF)
+    moved = []
+    for it in range(5):
+        before = prev.to_host()
+        engine.kmeans_accumulate(xd, centers, state, sums_i, counts_i, prev_labels=prev)
+        sums_f, counts_f = engine.zeros((k * d,), np.int64), engine.zeros((k,), np.int64)
+        engine.kmeans_accumulate(xd, centers, state, sums_f, counts_f)
+        np.testing.assert_array_equal(sums_i.to_host(), sums_f.to_host())
+        np.testing.assert_array_equal(counts_i.to_host(), counts_f.to_host())
+        lab = engine.kmeans_assign(xd, centers).to_host()
+        np.testing.assert_array_equal(prev.to_host(), lab)
+        moved.append(int((before != lab).sum()))
+        engine.kmeans_update(sums_i, counts_i, centers, state, clear=False)
+    assert moved[0] == n and moved[-1] < moved[1] < n          # fewer and fewer frames move
