@@ -118,6 +118,8 @@ __device__ __forceinline__ void cov_wave_body(const T* __restrict__ x, int F, in
     const int64_t q_end = min(q_begin + frames_per_wave, ft.total);
 
     using VT = T __attribute__((ext_vector_type(NT)));
+    const double w_int = 1.0 + ft.wy_w;          // weight of an interior frame in M00: 2 (reversible) or 1 (one-sided)
+    const double inv_w_int = 1.0 / w_int;        // 0.5 or 1: exact
     // Validity never masks the A operand: an out-of-segment lane re-reads the segment's
     // last frame (finite data) and its B operands carry weight 0, so it adds exact zeros.
     auto load_group = [&](int64_t t, int64_t s_start, int64_t s_stop, T (&rx)[NT], T (&ry)[NT], double& wx,
@@ -146,12 +148,16 @@ __device__ __forceinline__ void cov_wave_body(const T* __restrict__ x, int F, in
     // Left alone they drift apart by more than the CU's share of the L2 holds, and every row is then fetched from
     // memory twice (2.0x the algorithmic bytes in the round-1 FETCH_SIZE profile).  A rendezvous every 8 frame groups
     // through two LDS words keeps them within 16 groups (16 KB) of each other: the second reader hits L1 / L2.
+    // (the words are addressed as LDS explicitly: through the generic pointer they became flat loads, and a flat
+    // load waits for vmcnt(0) -- it drained the whole prefetch ring at every rendezvous)
+    typedef __attribute__((address_space(3))) volatile int* lds_words;
+    lds_words progl = (lds_words)prog;
     int my_groups = 0;
     auto rendezvous = [&]() {
         if constexpr (HALF >= 0) {
             if ((my_groups & 7) == 0) {
-                if (lane == 0) prog[2 * red_wave + HALF] = my_groups;
-                while (prog[2 * red_wave + (1 - HALF)] + 8 < my_groups) __builtin_amdgcn_s_sleep(1);
+                if (lane == 0) progl[2 * red_wave + HALF] = my_groups;
+                while (progl[2 * red_wave + (1 - HALF)] + 8 < my_groups) __builtin_amdgcn_s_sleep(1);
             }
             ++my_groups;
         }
@@ -162,38 +168,17 @@ __device__ __forceinline__ void cov_wave_body(const T* __restrict__ x, int F, in
         while (seg + 1 < ft.n && q0 >= ft.prefix[seg + 1]) ++seg;
         const int64_t s_start = ft.start[seg], s_stop = ft.stop[seg];
         const int64_t q_hi = min(q_end, ft.prefix[seg + 1]);   // this wave's share of the segment
-        int64_t t = s_start + (q0 - ft.prefix[seg]) + kk;
-        T rx[NT], ry[NT];
-        double wx, wy;
-        load_group(t, s_start, s_stop, rx, ry, wx, wy);
-        for (; q0 < q_hi; q0 += 4) {
-            rendezvous();
-            // consume the prefetched group into fp64 operands
-            double za[NT], zb[NT], zy[NT];
-            const double w = fma(ft.wy_w, wy, wx);
-#pragma unroll
-            for (int a = 0; a < NT; ++a) {
-                const double vx = to_f64(rx[a]);
-                const double vy = to_f64(ry[a]);
-                double cx = vx - shift[a];
-                double cy = vy - shift[a];
-                if constexpr (!FINITE) {  // NaN -> column mean
-                    if (!(vx == vx)) cx = 0.0;
-                    if (!(vy == vy)) cy = 0.0;
-                }
-                if constexpr (!VEC) {
-                    if (!fok[a]) { cx = 0.0; cy = 0.0; }
-                }
-                za[a] = cx;
-                zy[a] = wx * cy;
-                zb[a] = w * cx;
-                if constexpr (HALF <= 0) ssum[a] = fma(wx, cx, ssum[a]);
-                if constexpr (HALF == 1) ssum[a] = fma(wy, cx, ssum[a]);
-                if constexpr (HALF < 0) ssum2[a] = fma(wy, cx, ssum2[a]);
-            }
-            // next group's loads fly while the matrix cores work
-            t += 4;
-            if (q0 + 4 < q_hi) load_group(t, s_start, s_stop, rx, ry, wx, wy);
+        // Frame groups in the interior of a segment (all four frames have a partner lag frames later AND are
+        // partners themselves) need no weights and no clamped addresses.  fp64 vector instructions do not overlap
+        // fp64 matrix instructions on this chip (SQ_VALU_MFMA_COEXEC_CYCLES = 0 for this kernel, profiles/r02_pmc.md),
+        // so every vector instruction in the loop is matrix-pipe time lost: interior groups take 9 per feature pair
+        // (convert and centre both rows, one add for the column sum) and none for addresses -- the rows of a group
+        // come from one wave-uniform base plus a per-lane offset that never changes -- in a loop of their own, three
+        // groups in flight.  M00 is accumulated at 1 / (1 + wy_w) of its weight (the weight of an interior frame, a
+        // power of two) and scaled back when the wave hands in its tiles: exact, the bits are those of the weighted sum.
+        const int64_t len = s_stop - s_start;
+        const int64_t o_b = q0 - ft.prefix[seg], o_e = q_hi - ft.prefix[seg];   // wave-uniform group offsets, step 4
+        auto mfma_block = [&](const double (&za)[NT], const double (&zb)[NT], const double (&zy)[NT]) {
 #pragma unroll
             for (int a = 0; a < NT; ++a) {
 #pragma unroll
@@ -206,11 +191,98 @@ __device__ __forceinline__ void cov_wave_body(const T* __restrict__ x, int F, in
                         acc00[sym_index<NT>(a, b)] = __builtin_amdgcn_mfma_f64_16x16x4f64(
                             za[a], zb[b], acc00[sym_index<NT>(a, b)], 0, 0, 0);
             }
+        };
+        // groups [oa, ob) with weights and clamped rows: one group of look-ahead (segment heads and tails only)
+        auto run_general = [&](int64_t oa, int64_t ob) {
+            if (oa >= ob) return;
+            T rx[NT], ry[NT];
+            double wx, wy;
+            int64_t tt = s_start + oa + kk;
+            load_group(tt, s_start, s_stop, rx, ry, wx, wy);
+            for (int64_t og = oa; og < ob; og += 4) {
+                rendezvous();
+                double za[NT], zb[NT], zy[NT];
+                const double w = fma(ft.wy_w, wy, wx) * inv_w_int;
+#pragma unroll
+                for (int a = 0; a < NT; ++a) {
+                    const double vx = to_f64(rx[a]);
+                    const double vy = to_f64(ry[a]);
+                    double cx = vx - shift[a];
+                    double cy = vy - shift[a];
+                    if constexpr (!FINITE) {  // NaN -> column mean
+                        if (!(vx == vx)) cx = 0.0;
+                        if (!(vy == vy)) cy = 0.0;
+                    }
+                    if constexpr (!VEC) {
+                        if (!fok[a]) { cx = 0.0; cy = 0.0; }
+                    }
+                    za[a] = cx;
+                    zy[a] = wx * cy;
+                    zb[a] = w * cx;
+                    if constexpr (HALF <= 0) ssum[a] = fma(wx, cx, ssum[a]);
+                    if constexpr (HALF == 1) ssum[a] = fma(wy, cx, ssum[a]);
+                    if constexpr (HALF < 0) ssum2[a] = fma(wy, cx, ssum2[a]);
+                }
+                tt += 4;
+                if (og + 4 < ob) load_group(tt, s_start, s_stop, rx, ry, wx, wy);
+                mfma_block(za, zb, zy);
+            }
+        };
+        int64_t o_i0 = o_b, o_i1 = o_b;   // interior run [o_i0, o_i1) on the wave's own grid of groups
+        if constexpr (VEC) {
+            if (o_b < lag) o_i0 = o_b + ((lag - o_b + 3) / 4) * 4;
+            const int64_t lim = len - lag - 3;   // first offset whose last frame has no partner
+            o_i1 = lim > o_i0 ? o_i0 + ((lim - o_i0 + 3) / 4) * 4 : o_i0;
+            o_i0 = min(o_i0, o_e);
+            o_i1 = max(min(o_i1, o_e), o_i0);
         }
+        run_general(o_b, o_i0);
+        if constexpr (VEC) {
+            constexpr int kDepth = 3;
+            VT rx[kDepth], ry[kDepth];
+            const T* base = x + s_start * ld + (int64_t)kk * ld + NT * fi_;   // + og * ld per group
+            const int64_t lag_off = (int64_t)lag * ld;
+            auto load_inner = [&](int64_t og, int s) {
+                const T* px = base + og * ld;
+                rx[s] = *reinterpret_cast<const VT*>(px);
+                ry[s] = *reinterpret_cast<const VT*>(px + lag_off);
+            };
+#pragma unroll
+            for (int s = 0; s < kDepth; ++s)
+                if (o_i0 + 4 * s < o_i1) load_inner(o_i0 + 4 * s, s);
+            for (int64_t og = o_i0; og < o_i1;) {
+#pragma unroll
+                for (int s = 0; s < kDepth; ++s) {
+                    if (og >= o_i1) break;
+                    rendezvous();
+                    double za[NT], zy[NT];
+#pragma unroll
+                    for (int a = 0; a < NT; ++a) {
+                        const double vx = to_f64(rx[s][a]);
+                        const double vy = to_f64(ry[s][a]);
+                        double cx = vx - shift[a];
+                        double cy = vy - shift[a];
+                        if constexpr (!FINITE) {  // NaN -> column mean
+                            if (!(vx == vx)) cx = 0.0;
+                            if (!(vy == vy)) cy = 0.0;
+                        }
+                        za[a] = cx;
+                        zy[a] = cy;
+                        ssum[a] += cx;
+                        if constexpr (HALF < 0) ssum2[a] += cx;
+                    }
+                    if (og + 4 * kDepth < o_i1) load_inner(og + 4 * kDepth, s);
+                    mfma_block(za, za, zy);
+                    og += 4;
+                }
+            }
+        }
+        run_general(o_i1, o_e);
+        q0 = q_hi;
     }
 
     if constexpr (HALF >= 0) {
-        if (lane == 0) prog[2 * red_wave + HALF] = 0x7ffffff0;   // done: never hold the partner back
+        if (lane == 0) progl[2 * red_wave + HALF] = 0x7ffffff0;   // done: never hold the partner back
     }
     // ---- workgroup reduction: waves of a half add their tiles in wave order ----
     double* sums = red + S::kTiles * 256;  // [4][2][NT][64]
@@ -239,7 +311,7 @@ __device__ __forceinline__ void cov_wave_body(const T* __restrict__ x, int F, in
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const int idx = ((NT * NT + s) * 4 + r) * 64 + lane;
-                        red[idx] = (w == 0 ? 0.0 : red[idx]) + acc00[s][r];
+                        red[idx] = (w == 0 ? 0.0 : red[idx]) + w_int * acc00[s][r];
                     }
                 }
         }
