@@ -1214,18 +1214,22 @@ __global__ __launch_bounds__(kEigThreads) void tica_solve_kernel(
         for (int i = tid; i < n * n; i += nt) out_W[i] = 0.0;
         return;
     }
+    // 1 / scale and the means: in the LDS when they fit the solver's arrays (they are read 2 n times each below)
+    double* iscp = (lds_mats == 4 && n <= kTriMax) ? ts.lam : wk.isc;
+    double* meanp = (lds_mats == 4 && n <= kTriMax) ? ts.inv : wk.mean;
     for (int i = tid; i < n; i += nt) {
         const double is = scale ? 1.0 / scale[i] : 1.0;
-        wk.isc[i] = is;
-        wk.mean[i] = (sx[i] + sy[i]) / w * is;
-        out_mean[i] = wk.mean[i];
+        iscp[i] = is;
+        const double m = (sx[i] + sy[i]) / w * is;
+        meanp[i] = m;
+        out_mean[i] = m;
     }
     __syncthreads();
     auto build_cov = [&]() {
         for (int e = tid; e < n * n; e += nt) {
             const int i = e / n, j = e - i * n;
-            const double ss = wk.isc[i] * wk.isc[j];
-            const double mm = wk.mean[i] * wk.mean[j];
+            const double ss = iscp[i] * iscp[j];
+            const double mm = meanp[i] * meanp[j];
             A[i * ld + j] = 0.5 * (M00[e] + M00[j * n + i]) / w * ss - mm;   // C00
             B1[i * ld + j] = (M0t[e] + M0t[j * n + i]) / w * ss - mm;        // C0t
         }
@@ -1336,6 +1340,55 @@ __global__ __launch_bounds__(kEigThreads) void tica_solve_kernel(
     }
     __syncthreads();
     KSTAMP(11);
+    if (kFused && n <= kTriMax) {
+        // ---- the same tail with everything small in the LDS: eigenvalues, their order (|ev| descending, stable), the
+        // sign of every column of R = L Rt (its largest-magnitude entry, first occurrence, made positive); the signs
+        // and the kinetic-map factors are applied on the way out instead of in place
+        double* evl = ts.praw;      // eigenvalues in solver order
+        double* sgn = ts.uq;        // +-1 per solver column
+        int* ord = sh.p;            // ord[j] = solver column of the j-th largest |ev|
+        if (tid < rank) evl[tid] = wk.ev[tid];
+        __syncthreads();
+        if (tid < rank) {
+            const double a = fabs(evl[tid]);
+            int r = 0;
+            for (int j = 0; j < rank; ++j) {
+                const double b = fabs(evl[j]);
+                r += (b > a) || (b == a && j < tid);
+            }
+            ord[r] = tid;
+        }
+        mfma_mm<false, false>(B1, B2, Vec, n, rank, rank, ld);   // columns still in solver order (barrier inside)
+        {
+            const int lane = tid & 63, wave = tid >> 6;
+            for (int j = wave; j < rank; j += nt >> 6) {          // one wave per column, lane = row
+                double best = lane < n ? fabs(B1[lane * ld + j]) : -1.0;
+                int bi = lane;
+                double val = lane < n ? B1[lane * ld + j] : 0.0;
+#pragma unroll
+                for (int off = 1; off < 64; off <<= 1) {
+                    const double ob = __shfl_xor(best, off, 64), ov = __shfl_xor(val, off, 64);
+                    const int oi = __shfl_xor(bi, off, 64);
+                    if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; val = ov; }
+                }
+                if (lane == 0) sgn[j] = val < 0.0 ? -1.0 : 1.0;
+            }
+        }
+        __syncthreads();
+        for (int e = tid; e < n * n; e += nt) {
+            const int i = e / n, j = e - i * n;
+            double v = 0.0;
+            if (j < rank) {
+                const int c = ord[j];
+                v = B1[i * ld + c] * sgn[c];
+                if (kinetic_map) v *= evl[c];
+            }
+            out_W[e] = v;
+        }
+        for (int j = tid; j < n; j += nt) out_eig[j] = j < rank ? evl[ord[j]] : 0.0;
+        KSTAMP(12);
+        return;
+    }
     sort_desc_abs(wk.ev, rank, wk.order);
     // ---- R = L Rt (sorted), canonical signs, kinetic map ----
     mfma_mm<false, false>(B1, B2, Vec, n, rank, rank, ld);   // columns still in solver order
