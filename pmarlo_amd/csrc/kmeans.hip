@@ -870,21 +870,10 @@ template <typename T, int NM, bool ACCUM>
 msm_status launch_filter_nm(msm_ctx* ctx, const T* x, int64_t n, int d, int64_t ld, const double* centers, int k,
                             const double* mean, const double* stdv, const uint4* image, int32_t* labels, double* mindist,
                             const FitState* st, unsigned long long* sums, unsigned long long* counts) {
-    using S = FilterShape<NM>;
     constexpr int NF = 4;
     const size_t lds = filter_lds_bytes(k, d, ACCUM);
-    const int k16 = (k + 15) & ~15;
-    const int n_tiles = ((k16 / 16) + 1) & ~1;
-    // staged centre tables: image | fp64 rows | guard flag
-    const size_t img_bytes = (size_t)n_tiles * NM * 1024, cs_bytes = (size_t)n_tiles * 16 * S::D1 * sizeof(double);
-    msm_status rs = msm_reserve_aux(ctx, img_bytes + cs_bytes + (size_t)n_tiles * sizeof(int));
-    if (rs != MSM_OK) return rs;
-    uint4* img_g = (uint4*)ctx->aux;
-    double* cs_g = (double*)((char*)ctx->aux + img_bytes);
-    int* flag = (int*)((char*)ctx->aux + img_bytes + cs_bytes);   // one word per tile, rewritten by every launch
-    hipLaunchKernelGGL((kmeans_filter_stage_kernel<NM>), dim3(n_tiles), dim3(64), 0, ctx->stream, centers, k, d, img_g, cs_g,
-                       flag);
-    MSM_CHECK_LAUNCH(ctx);
+    // (the centre tables are built by every workgroup of the kernel for itself: no staging launch)
+    msm_status rs;
     const int64_t n_units = (n + 16 * NF - 1) / (16 * NF);
     const int grid = (int)std::min<int64_t>((n_units + 15) / 16, (int64_t)ctx->n_cu);
     unsigned long long* stats = nullptr;
@@ -893,9 +882,8 @@ msm_status launch_filter_nm(msm_ctx* ctx, const T* x, int64_t n, int d, int64_t 
     auto kern = mean ? kmeans_filter_kernel<T, NM, NF, ACCUM, true> : kmeans_filter_kernel<T, NM, NF, ACCUM, false>;
     if (lds > 48 * 1024)
         MSM_HIP(ctx, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(1024), lds, ctx->stream, x, n, d, ld, k, mean, stdv, image,
-                       (const uint4*)img_g, (const double*)cs_g, (const int*)flag, labels, mindist, st, sums, counts, stats,
-                       filter_stagger());
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(1024), lds, ctx->stream, x, n, d, ld, k, mean, stdv, image, centers, labels,
+                       mindist, st, sums, counts, stats, filter_stagger());
     MSM_CHECK_LAUNCH(ctx);
     return MSM_OK;
 }

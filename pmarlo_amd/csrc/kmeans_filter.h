@@ -153,12 +153,13 @@ __global__ __launch_bounds__(256) void kmeans_pack_kernel(const T* __restrict__ 
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// Centre side, once per launch (kmeans_filter_stage_kernel, one workgroup per 16-centre tile) into global memory:
+// Centre side, once per launch and workgroup (filter_stage_tile, one wave per 16-centre tile) into the kernel's LDS:
 //   img   [n_tiles][NM][64] uint4      A operands, lane-major per instruction
 //   cs64  [n_tiles * 16][DP + 2] f64   centre coordinates zero-padded to DP features, then h_j (+inf for padding
 //                                      rows), then one pad double (rows are 16-byte aligned): refinement and scan
 //   flag  int [n_tiles]                a centre of the tile failed the range guard: every frame takes the exhaustive scan
-// The main kernel copies img + cs64 into its LDS with 16-byte loads.  DP = 4 (NM = 1) or 10 (NM = 2): the fp64
+// (Each workgroup builds the tables for itself: as fast as copying 113 KB of ready tables from a staging launch, and
+// one launch less per pass.)  DP = 4 (NM = 1) or 10 (NM = 2): the fp64
 // chains run over DP features with zeros beyond d, which leaves every partial sum unchanged.
 // ---------------------------------------------------------------------------------------------------------
 template <int NM>
@@ -168,7 +169,8 @@ struct FilterShape {
     static constexpr int kTileBytes = NM * 1024 + 16 * D1 * 8;    // image + table rows of one 16-centre tile
 };
 
-// One wave stages one 16-centre tile (simg: NM * 64 * 8 shorts of LDS of its own).  `centers` may be global or LDS.
+// One wave stages one 16-centre tile (simg: NM * 64 * 8 shorts of LDS of its own).  `centers`, `cs_g` and `flag` may
+// be global or LDS; the table rows go to cs_g + j * D1.
 template <int NM>
 __device__ __forceinline__ void filter_stage_tile(int tile, int lane, unsigned short* simg, const double* centers, int k,
                                                   int d, uint4* __restrict__ img_g, double* __restrict__ cs_g,
@@ -222,17 +224,10 @@ __device__ __forceinline__ void filter_stage_tile(int tile, int lane, unsigned s
         }
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    for (int i = lane; i < NM * 64; i += 64) img_g[(size_t)tile * NM * 64 + i] = reinterpret_cast<const uint4*>(simg)[i];
-    const bool any_bad = __any(bad_row != 0);      // every launch rewrites its flag
+    if (img_g)   // NULL: `simg` is the image's final place (the main kernel stages into its own LDS)
+        for (int i = lane; i < NM * 64; i += 64) img_g[(size_t)tile * NM * 64 + i] = reinterpret_cast<const uint4*>(simg)[i];
+    const bool any_bad = __any(bad_row != 0);      // every staging rewrites its flag
     if (lane == 0) flag[tile] = any_bad ? 1 : 0;
-}
-
-template <int NM>
-__global__ __launch_bounds__(64) void kmeans_filter_stage_kernel(const double* __restrict__ centers, int k, int d,
-                                                                uint4* __restrict__ img_g, double* __restrict__ cs_g,
-                                                                int* __restrict__ flag) {
-    __shared__ __attribute__((aligned(16))) unsigned short simg[NM * 64 * 8];
-    filter_stage_tile<NM>(blockIdx.x, threadIdx.x, simg, centers, k, d, img_g, cs_g, flag);
 }
 
 // cross-row butterflies over the 4 lanes (j, j + 16, j + 32, j + 48) that share a frame: v_permlane16_swap /
@@ -283,8 +278,8 @@ __device__ __forceinline__ void xrow_argmax_f64(double& best, int& bi) {
 template <typename T, int NM, int NF, bool ACCUM, bool WHITEN>
 __global__ __launch_bounds__(1024, 4) void kmeans_filter_kernel(
     const T* __restrict__ x, int64_t n, int d, int64_t ld, int k, const double* __restrict__ mean,
-    const double* __restrict__ stdv, const uint4* __restrict__ image, const uint4* __restrict__ img_g,
-    const double* __restrict__ cs_g, const int* __restrict__ flag_g, int32_t* __restrict__ labels,
+    const double* __restrict__ stdv, const uint4* __restrict__ image, const double* __restrict__ centers,
+    int32_t* __restrict__ labels,
     double* __restrict__ mindist, const FitState* __restrict__ st, unsigned long long* __restrict__ sums,
     unsigned long long* __restrict__ counts, unsigned long long* __restrict__ n_scanned, int stagger) {
     using S = FilterShape<NM>;
@@ -308,16 +303,17 @@ __global__ __launch_bounds__(1024, 4) void kmeans_filter_kernel(
     if constexpr (ACCUM) {
         for (int i = tid; i < k * (d + 1); i += kMT) lsum[i] = 0ull;
     }
-    // ---- copy the staged centre tables (16-byte vectors, four in flight per thread)
+    // ---- centre tables, built by every workgroup for itself: wave w stages tiles w, w + 16, ... straight into the
+    // LDS (a separate staging launch + 113 KB of copies per workgroup did the same for 4.7 us more per pass)
+    __shared__ int tile_flag[64];
     {
-        const int nv_img = n_tiles * NM * 64, nv_cs = n_tiles * 16 * D1 / 2;
-        uint4* cs64v = reinterpret_cast<uint4*>(cs64);
-        const uint4* cs_gv = reinterpret_cast<const uint4*>(cs_g);
-        for (int i = tid; i < nv_img; i += kMT) img[i] = img_g[i];
-        for (int i = tid; i < nv_cs; i += kMT) cs64v[i] = cs_gv[i];
+        for (int t = wave; t < n_tiles; t += kMT / 64)   // padding tiles too: their rows carry the -inf sentinel
+            filter_stage_tile<NM>(t, lane, reinterpret_cast<unsigned short*>(img + (size_t)t * NM * 64), centers, k, d,
+                                  nullptr, cs64, tile_flag);
     }
+    __syncthreads();
     int bad_tiles = 0;
-    for (int t = 0; t < n_tiles; ++t) bad_tiles |= flag_g[t];
+    for (int t = 0; t < n_tiles; ++t) bad_tiles |= tile_flag[t];
     const bool all_scan = bad_tiles != 0;
     __syncthreads();
     KSTAMP(0);
