@@ -693,7 +693,11 @@ __device__ __forceinline__ void householder_phase(double* A, double* QT, int n, 
     constexpr int ld = kTriLd;
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const bool in = lane < n;
+#ifdef MSM_TRI_NOQ   // diagnostic build only (tools/probe/tri_probe.hip): what the tridiagonalisation costs without its Q waves
+    const int role = wave < 4 ? 0 : 2;
+#else
     const int role = wave < 4 ? 0 : (wave < 8 ? 1 : 2);
+#endif
     const int sub = wave & 3;
     double* part = ts->part[(role == 1 ? 4 : 0) + sub];
     const double* parts = ts->part[role == 1 ? 4 : 0];
