@@ -425,31 +425,6 @@ __device__ void canonical_signs(double* M, int n, int ncols, int ld) {
     __syncthreads();
 }
 
-// In-place Cholesky M = G G' (lower triangle of M becomes G).  Returns false (uniformly) as
-// soon as a pivot is not positive.  Block-parallel right-looking form, 3 barriers per column.
-__device__ bool cholesky_lower(double* M, int n, int ld, JacobiShared* sh) {
-    const int tid = threadIdx.x, nt = blockDim.x;
-    for (int j = 0; j < n; ++j) {
-        if (tid == 0) {
-            const double dj = M[j * ld + j];
-            sh->ibc[1] = dj > 0.0 ? 1 : 0;
-            if (dj > 0.0) M[j * ld + j] = sqrt(dj);
-        }
-        __syncthreads();
-        if (!sh->ibc[1]) return false;
-        const double gjj = M[j * ld + j];
-        for (int i = j + 1 + tid; i < n; i += nt) M[i * ld + j] /= gjj;
-        __syncthreads();
-        const int m = n - j - 1;
-        for (int e = tid; e < m * m; e += nt) {
-            const int a = e / m, b = e - a * m;  // trailing (j+1+a, j+1+b), lower part only
-            if (b <= a) M[(j + 1 + a) * ld + (j + 1 + b)] -= M[(j + 1 + a) * ld + j] * M[(j + 1 + b) * ld + j];
-        }
-        __syncthreads();
-    }
-    return true;
-}
-
 // Two factorisations in lockstep (same barriers): P = chol(Mp) is only a positive-definiteness
 // probe, Q = chol(Mq) is the factor that is used.  Returns false as soon as Mp loses a pivot
 // (Mq is then unfinished and must not be used).
@@ -1140,44 +1115,6 @@ __device__ __forceinline__ bool tridiag_eigh(double* A, double* Q, double* X, in
     if (tid < n) ts->lam[tid] /= ts->scale;
     __syncthreads();
     TSTAMP(7);
-    return true;
-}
-
-// Fused LDL' factorisations and unit-lower inverse, ONE barrier per column:
-//   Mp = Lp Dp Lp'  (positive-definiteness probe only: fails as soon as a pivot is not positive)
-//   Mq = L D L',  X = L^-1  (X must hold the identity on entry)
-// Column j is never touched after step j - 1, so step j reads it (and the pivot) without a barrier of its own:
-// trailing update M[a][b] -= M[a][j] M[b][j] / d_j (lower triangle), X[i][c] -= (M[i][j] / d_j) X[j][c].
-// On success the diagonal of Mq holds D and its strict lower triangle the UNSCALED columns (L[i][j] d_j).
-__device__ __forceinline__ bool ldl_inverse_pair(double* Mp, double* Mq, double* X, int n, int ld) {
-    // thread (ty, tx) owns column tx of the rows ty, ty + nty, ...: no index arithmetic beyond adds, and the strict
-    // upper triangle of the trailing matrices is never touched
-    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6, nty = blockDim.x >> 6;
-    LSTAMP_INIT
-    for (int j = 0; j < n; ++j) {
-        const double pj = Mp[j * ld + j], qj = Mq[j * ld + j];
-        if (!(pj > 0.0) || !(qj > 0.0)) return false;   // every thread reads the same two numbers
-        const double ip = nr_rcp(pj), iq = nr_rcp(qj);
-        LSTAMP(13);
-        for (int c = tx; c < n; c += 64) {
-            if (c > j) {   // trailing update, lower triangle: rows i >= c
-                const double pc = Mp[c * ld + j], qc = Mq[c * ld + j];
-                for (int i = ty; i < n; i += nty) {
-                    if (i >= c) {
-                        Mp[i * ld + c] = fma(-(Mp[i * ld + j] * ip), pc, Mp[i * ld + c]);
-                        Mq[i * ld + c] = fma(-(Mq[i * ld + j] * iq), qc, Mq[i * ld + c]);
-                    }
-                }
-            } else {       // X[i][c] -= l_ij X[j][c] for the rows below j (X is lower triangular: c <= j)
-                const double xj = X[j * ld + c];
-                for (int i = ty; i < n; i += nty)
-                    if (i > j) X[i * ld + c] = fma(-(Mq[i * ld + j] * iq), xj, X[i * ld + c]);
-            }
-        }
-        LSTAMP(14);
-        __syncthreads();
-        LSTAMP(15);
-    }
     return true;
 }
 
