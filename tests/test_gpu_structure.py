@@ -103,3 +103,48 @@ def test_dssp_matches_the_oracle(engine, protein):
     assert frac.shape == (protein.n_frames, 3)
     np.testing.assert_allclose(frac.sum(axis=1), 1.0, atol=1e-12)
     assert (frac[:, 0] > 0.5).all() and (frac[:, 1] < 0.1).all()
+
+
+def test_structure_features_edge_cases(engine, protein):
+    """No hydrogens -> no donors -> count 0; a residue without a backbone atom or a non-protein residue -> 'NA' (counted
+    in the ssfrac denominator, as the reference does); two chains: no helix across the break; zero frames."""
+    from pmarlo_amd.io.pdb import Topology
+
+    n_res = 14
+    xyz = _ideal_helix(n_res)                                   # N, CA, C, O per residue
+    names = ["N", "CA", "C", "O"] * n_res
+    resn = [nm for r in range(n_res) for nm in [("HOH" if r == 5 else "ALA")] * 4]
+    res_index = np.repeat(np.arange(n_res), 4)
+    chains = ["A"] * (4 * 7) + ["B"] * (4 * 7)
+    top = Topology(names, resn, res_index, chains, elements=["N", "C", "C", "O"] * n_res)
+    traj = Trajectory(np.repeat(xyz, 3, axis=0), top)
+    assert len(st.hbond_triplets(traj)) == 0
+    np.testing.assert_array_equal(get_feature("hbonds_count").compute(traj), np.zeros((3, 1)))
+    codes = st.compute_dssp(traj)
+    assert codes.shape == (3, n_res) and (codes[:, 5] == "NA").all()
+    keep, table, chain, proline = st.backbone_table(top)
+    assert 5 not in keep and len(keep) == n_res - 1
+    full = engine.dssp(engine.to_device(traj.xyz), table, chain, proline)
+    np.testing.assert_array_equal(full, npport.dssp_codes(traj.xyz, table, chain, proline))
+    # residue 5 is missing and the chain changes after residue 6: the two stretches are too short for a full turn pair
+    frac = get_feature("ssfrac").compute(traj)
+    np.testing.assert_allclose(frac.sum(axis=1), 1.0, atol=1e-12)
+    # zero frames
+    empty = Trajectory(np.zeros((0, 4 * n_res, 3), np.float32), top)
+    assert st.shrake_rupley(empty).shape == (0, 4 * n_res)
+    assert st.compute_dssp(empty).shape == (0, n_res)
+    assert get_feature("sasa").compute(empty).shape == (0, 1)
+    # an element without a radius: the feature returns zeros, as the reference does when mdtraj raises
+    odd = Topology(names, ["ALA"] * (4 * n_res), res_index, ["A"] * (4 * n_res), elements=["Xx"] * (4 * n_res))
+    np.testing.assert_array_equal(get_feature("sasa").compute(Trajectory(traj.xyz, odd)), np.zeros((3, 1)))
+
+
+def test_baker_hubbard_frequency_threshold(engine):
+    traj = _water_free_dipeptide()                               # 5 frames, the bond present in all
+    assert len(st.baker_hubbard(traj, freq=0.1)) == 1
+    xyz = traj.xyz.copy()
+    xyz[:4, 3] = [0.12, 0.17, 0.0]                               # present in 1 of 5 frames only
+    t2 = Trajectory(xyz, traj.topology)
+    assert len(st.baker_hubbard(t2, freq=0.1)) == 1              # 0.2 > 0.1
+    assert len(st.baker_hubbard(t2, freq=0.2)) == 0              # strictly greater
+    assert len(st.baker_hubbard(t2, freq=0.0)) == 1
