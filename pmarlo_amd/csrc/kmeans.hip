@@ -178,6 +178,53 @@ __global__ __launch_bounds__(1024) void kmeans_update_kernel(unsigned long long*
     }
 }
 
+// The same update for wide tables (k d above kUpdateWide: C5 has 512 k elements, 387 us in one workgroup): whole
+// centres dealt out to workgroups, each leaving its share of shift2 (summed as in the one-workgroup kernel) in
+// `partial`; a finishing launch adds the shares in workgroup order and closes the iteration.
+constexpr int kUpdateWide = 16384;
+__global__ __launch_bounds__(1024) void kmeans_update_wide_kernel(unsigned long long* __restrict__ sums,
+                                                                 unsigned long long* __restrict__ counts, int k, int d,
+                                                                 int centres_per_block, double* __restrict__ centers,
+                                                                 const FitState* __restrict__ st, int clear,
+                                                                 double* __restrict__ partial) {
+    __shared__ double red[16];
+    if (st->done != 0.0) return;
+    const double inv_scale = st->inv_scale;
+    const int j0 = blockIdx.x * centres_per_block, j1 = min(k, j0 + centres_per_block);
+    const int64_t e0 = (int64_t)j0 * d, e1 = (int64_t)j1 * d;
+    double acc = 0.0;
+    for (int64_t i = e0 + threadIdx.x; i < e1; i += blockDim.x) {
+        const int j = (int)(i / d);
+        const long long cnt = (long long)counts[j];
+        if (cnt > 0) {
+            const double c_new = (double)(long long)sums[i] * inv_scale / (double)cnt;
+            const double dlt = c_new - centers[i];
+            acc = fma(dlt, dlt, acc);
+            centers[i] = c_new;
+        }
+    }
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (clear) {
+        for (int64_t i = e0 + threadIdx.x; i < e1; i += blockDim.x) sums[i] = 0ull;
+        for (int j = j0 + threadIdx.x; j < j1; j += blockDim.x) counts[j] = 0ull;
+    }
+    if (threadIdx.x == 0) {
+        double t = 0.0;
+        for (int i = 0; i < (int)(blockDim.x >> 6); ++i) t += red[i];
+        partial[blockIdx.x] = t;
+    }
+}
+__global__ void kmeans_update_finish_kernel(const double* __restrict__ partial, int nb, FitState* __restrict__ st) {
+    if (threadIdx.x != 0 || blockIdx.x != 0 || st->done != 0.0) return;
+    double t = 0.0;
+    for (int i = 0; i < nb; ++i) t += partial[i];
+    st->shift2 = t;
+    st->n_iter += 1.0;
+    if (t <= st->tol2) st->done = 1.0;
+}
+
 // inertia = sum(mindist) with a fixed-order two-level reduction
 __global__ __launch_bounds__(1024) void sum_partial_kernel(const double* __restrict__ v, int64_t n,
                                                           double* __restrict__ partial) {
@@ -1088,6 +1135,21 @@ msm_status msm_kmeans_update(msm_ctx* ctx, int64_t* d_sums, int64_t* d_counts, i
     if (!ctx) return MSM_ERR_INVALID;
     MSM_REQUIRE(ctx, k >= 1 && d >= 1, "msm_kmeans_update: bad shape");
     MSM_REQUIRE(ctx, d_sums && d_counts && d_centers && d_state, "msm_kmeans_update: NULL pointer");
+    if ((int64_t)k * d > kUpdateWide) {
+        const int nb = std::min(k, ctx->n_cu);
+        const int cpb = (k + nb - 1) / nb;
+        const int nblocks = (k + cpb - 1) / cpb;
+        msm_status rs = msm_reserve_aux(ctx, (size_t)nblocks * sizeof(double));
+        if (rs != MSM_OK) return rs;
+        hipLaunchKernelGGL(kmeans_update_wide_kernel, dim3(nblocks), dim3(1024), 0, ctx->stream, (unsigned long long*)d_sums,
+                           (unsigned long long*)d_counts, k, d, cpb, d_centers, (const FitState*)d_state, clear,
+                           (double*)ctx->aux);
+        MSM_CHECK_LAUNCH(ctx);
+        hipLaunchKernelGGL(kmeans_update_finish_kernel, dim3(1), dim3(64), 0, ctx->stream, (const double*)ctx->aux, nblocks,
+                           (FitState*)d_state);
+        MSM_CHECK_LAUNCH(ctx);
+        return MSM_OK;
+    }
     hipLaunchKernelGGL(kmeans_update_kernel, dim3(1), dim3(1024), 0, ctx->stream, (unsigned long long*)d_sums,
                        (unsigned long long*)d_counts, k, d, d_centers, (FitState*)d_state, clear);
     MSM_CHECK_LAUNCH(ctx);
