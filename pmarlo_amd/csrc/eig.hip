@@ -789,11 +789,16 @@ __device__ __forceinline__ void householder_phase(double* A, double* QT, int n, 
 // total: 1.5 per row here.
 // On success W = (D^-1/2 L^-1)' (upper triangular, W' C00 W = I) is written to `W`; false (uniformly) as soon as a pivot
 // of either matrix is not positive.  C is left as it was.  blockDim.x >= 768.
-__device__ __forceinline__ bool ldl_whiten_registers(const double* C, double* W, int n, double epsilon, TriShared* ts) {
+// mode 0: both eliminations; 1: C00 and X only (the caller certifies full rank from W, see tica_solve_kernel);
+// 2: the probe alone (waves 0-3), nothing is written to W.
+__device__ __forceinline__ bool ldl_whiten_registers(const double* C, double* W, int n, double epsilon, TriShared* ts,
+                                                     int mode) {
     constexpr int ld = kTriLd;
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const bool in = lane < n;
-    const int what = wave >> 2;   // 0: C00, 1: X, 2: probe, 3: nothing
+    // 0: C00, 1: X, 2: probe, 3: nothing
+    const int what = mode == 2 ? (wave < 4 ? 2 : 3) : (mode == 1 ? (wave < 8 ? wave >> 2 : 3) : wave >> 2);
+    const bool both = mode == 0;
     const int sub = wave & 3;
     double m[16];
 #pragma unroll
@@ -812,8 +817,8 @@ __device__ __forceinline__ bool ldl_whiten_registers(const double* C, double* W,
             // elimination: every wave sees both pivots, so all of them leave together when one is not positive
             const double rowM = ts->part[par + (what == 2 ? 2 : 0)][lane];
             const double row = what == 1 ? ts->part[par + 1][lane] : rowM;
-            const double rowO = ts->part[par + (what == 2 ? 0 : 2)][lane];
-            const double d = bcast_lane(rowM, j), dO = bcast_lane(rowO, j);
+            const double rowO = both ? ts->part[par + (what == 2 ? 0 : 2)][lane] : 1.0;
+            const double d = bcast_lane(rowM, j), dO = both ? bcast_lane(rowO, j) : 1.0;
             LSTAMP(13);
             if (!(d > 0.0) || !(dO > 0.0)) return false;   // uniform over the workgroup (see below for the idle waves)
             {
@@ -842,7 +847,7 @@ __device__ __forceinline__ bool ldl_whiten_registers(const double* C, double* W,
                 }
             }
         } else {   // waves without rows: the same two pivots, the same decision
-            const double dM = ts->part[par][j], dP = ts->part[par + 2][j];
+            const double dM = mode == 2 ? 1.0 : ts->part[par][j], dP = mode == 1 ? 1.0 : ts->part[par + 2][j];
             if (!(dM > 0.0) || !(dP > 0.0)) return false;
         }
         LSTAMP(14);
@@ -1188,7 +1193,19 @@ __global__ __launch_bounds__(kEigThreads) void tica_solve_kernel(
     constexpr bool kFused = lds_mats == 4;   // fused LDL' + inverse (one barrier per column) and the tridiagonal solver
     bool full_rank;
     if (kFused && n <= kTriMax) {
-        full_rank = ldl_whiten_registers(A, B2, n, epsilon, &ts);   // B2 = whitening (upper triangular); C00 stays in A
+        // B2 = whitening W (upper triangular, W' C00 W = I); C00 stays in A.  C00^-1 = W W', so lambda_min(C00) >=
+        // 1 / trace(W W') = 1 / ||W||_F^2: when that already clears epsilon every eigen-direction is kept and the
+        // elimination of the probe C00 - epsilon I (a third of the phase's instructions) is not needed
+        full_rank = ldl_whiten_registers(A, B2, n, epsilon, &ts, 1);
+        if (full_rank) {
+            double s = 0.0;
+            for (int e = tid; e < n * n; e += nt) {
+                const double wv = B2[(e / n) * ld + (e % n)];
+                s = fma(wv, wv, s);
+            }
+            s = block_sum(s, &sh);
+            if (!(s * epsilon * (1.0 + 1e-9) <= 1.0)) full_rank = ldl_whiten_registers(A, nullptr, n, epsilon, &ts, 2);
+        }
     } else {
         for (int e = tid; e < n * n; e += nt) {
             const int i = e / n, j = e - i * n;

@@ -194,6 +194,21 @@ def test_tica_rank_deficient_input(engine):
     assert np.all(eig[rank:] == 0) and np.all(W[:, rank:] == 0)
 
 
+@pytest.mark.parametrize("var_small,rank_want", [(1.5e-6, 8), (0.6e-6, 6)])
+def test_tica_directions_near_the_epsilon_cut(engine, var_small, rank_want):
+    """Two directions whose variance sits just above / below deeptime's epsilon = 1e-6.  Above: the cheap certificate
+    lambda_min >= 1 / ||W||_F^2 is too coarse (2 / 1.5e-6 > 1e6), so the elimination of the probe C00 - epsilon I must
+    run and keep the full rank; below: the probe fails and the eigen path cuts the two directions."""
+    rng = np.random.default_rng(3)
+    X = _gen.correlated_series(20_000, 6, seed=17).astype(np.float64)
+    X = X / X.std(axis=0)
+    X = np.hstack([X, rng.normal(0.0, np.sqrt(var_small), size=(20_000, 2))])
+    eig, W, m2, rank, Y = _tica_gpu(engine, X, 5, 3, scale=False)
+    model = npport.tica_fit([npport.preprocess(X, scale=False)], 5, dim=3)
+    assert rank == model["rank"] == rank_want
+    np.testing.assert_allclose(eig[:rank], model["eigenvalues"], rtol=1e-7, atol=1e-9)
+
+
 def test_tica_multi_trajectory_segments(engine):
     """_maybe_apply_tica fits on a list of trajectories: pairs never cross a boundary."""
     parts = [_gen.correlated_series(m, 12, seed=s) for m, s in [(3000, 1), (50, 2), (4000, 3), (8, 4)]]
