@@ -244,6 +244,15 @@ msm_status msm_lagged_moments(msm_ctx* ctx, const void* d_x, msm_dtype dtype, in
                               const int64_t* h_seg_start, const int64_t* h_seg_stop, int n_seg, int lag,
                               const double* d_shift, int assume_finite, double* d_moments);
 
+/* The same pass with the M0t block SYMMETRISED: the slot holds (M0t + M0t') / 2, everything else as above.  That is
+ * all the reversible estimator reads of M0t (deeptime forms C0t = (X'Y + Y'X) / 2T), and it is cheaper: for
+ * 32 < F <= 64 the kernel accumulates S = sum_pairs (z_t + z_{t+lag})(z_t + z_{t+lag})' and M00, both symmetric
+ * (2 x F(F+16)/2 multiply-adds per frame instead of F^2 + F(F+16)/2), and finishes with (S - M00) / 2; other shapes
+ * run the plain pass and symmetrise in place.  Still additive over shards. */
+msm_status msm_lagged_moments_reversible(msm_ctx* ctx, const void* d_x, msm_dtype dtype, int64_t n, int F, int64_t ld,
+                                         const int64_t* h_seg_start, const int64_t* h_seg_stop, int n_seg, int lag,
+                                         const double* d_shift, int assume_finite, double* d_moments);
+
 /* The same pass with ONE-SIDED second moments: M00 = sum over X0 only (M0t, sx, sy, T as above).
  * What the reference's in-repo TICA eigenvalue estimator needs (separate means and covariance of
  * y_t: _estimate_top_eigenvalues, S/features/deeptica/core/trainer_api.py:641-646). */

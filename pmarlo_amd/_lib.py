@@ -70,6 +70,7 @@ _PROTOTYPES: dict[str, tuple] = {
     "msm_standardise_params": (_i32, [_vp, _vp, _vp, _i32, _f64, _i32, _vp, _vp, _vp]),
     "msm_lagged_moments": (_i32, [_vp, _vp, _i32, _i64, _i32, _i64, _vp, _vp, _i32, _i32, _vp, _i32, _vp]),
     "msm_tica_solve": (_i32, [_vp, _vp, _vp, _i32, _f64, _i32, _vp, _vp, _vp, _vp]),
+    "msm_lagged_moments_reversible": (_i32, [_vp, _vp, _i32, _i64, _i32, _i64, _vp, _vp, _i32, _i32, _vp, _i32, _vp]),
     "msm_lagged_moments_onesided": (_i32, [_vp, _vp, _i32, _i64, _i32, _i64, _vp, _vp, _i32, _i32, _vp, _i32, _vp]),
     "msm_onesided_tica_eigenvalues": (_i32, [_vp, _vp, _i32, _f64, _vp]),
     "msm_moments_from_lagged": (_i32, [_vp, _vp, _i32, _i64, _i32, _i64, _vp, _vp, _i32, _i32, _vp, _vp, _vp]),

@@ -80,17 +80,27 @@ struct TileSplit {
     template <int HALF> static constexpr bool own_00(int sidx) { return HALF < 0 || (HALF == 0) == (sidx < kSym0); }
 };
 
+// Symmetric flavour (reversible estimator only): the wave pair accumulates S = sum wx (zx + zy)(zx + zy)' and M00, both
+// symmetric -- 2 x kSym tiles instead of NT^2 + kSym (20 instead of 26 at F = 64) -- and the finishing kernel forms
+// (M0t + M0t') / 2 = (S - M00) / 2, which is all the reversible TICA ever reads of M0t.  S lives in the M0t tile slots
+// (a, b), a <= b; half 0 owns S, half 1 owns M00 and both column sums.
+template <int NT>
+struct TileSplitSym {
+    template <int HALF> static constexpr bool own_0t(int) { return HALF <= 0; }
+    template <int HALF> static constexpr bool own_00(int) { return HALF != 0; }
+};
+
 // Feature <-> (tile, row) map.  The contraction does not care which 16 features form a
 // "tile", so tile a holds features {NT*i + a : i = 0..15}: lane i then needs features
 // NT*i .. NT*i + NT-1 of its frame, ONE contiguous load of NT elements (16 bytes for
 // fp32 at F = 64), and 16 lanes cover a whole 64-feature row.
-template <typename T, int NT, bool VEC, int HALF, bool FINITE>
+template <typename T, int NT, bool VEC, int HALF, bool FINITE, bool SYM = false>
 __device__ __forceinline__ void cov_wave_body(const T* __restrict__ x, int F, int64_t ld, const FrameTab& ft,
                                               const double* __restrict__ mu, int64_t frames_per_wave,
                                               int frame_wave, int n_frame_waves, double* red, int red_wave,
                                               volatile int* prog = nullptr) {
     using S = CovShape<NT>;
-    using TS = TileSplit<NT>;
+    using TS = std::conditional_t<SYM, TileSplitSym<NT>, TileSplit<NT>>;
     const int lane = threadIdx.x & 63;
     const int fi_ = lane & 15;
     const int kk = lane >> 4;
@@ -100,12 +110,13 @@ __device__ __forceinline__ void cov_wave_body(const T* __restrict__ x, int F, in
     v4f64 acc00[S::kSym];
     double ssum[NT], shift[NT];  // HALF 0 sums X0 (sx), HALF 1 sums Yt (sy); HALF < 0 keeps both
     double ssum2[NT];
+    double sint[NT];             // SYM: column sums over interior groups (they count for sx and sy alike)
     bool fok[NT];
 #pragma unroll
     for (int a = 0; a < NT; ++a) {
 #pragma unroll
         for (int b = 0; b < NT; ++b) acc0t[a][b] = (v4f64){0.0, 0.0, 0.0, 0.0};
-        ssum[a] = ssum2[a] = 0.0;
+        ssum[a] = ssum2[a] = sint[a] = 0.0;
         const int f = NT * fi_ + a;
         fok[a] = f < F;
         shift[a] = fok[a] ? mu[f] : 0.0;
@@ -154,6 +165,7 @@ __device__ __forceinline__ void cov_wave_body(const T* __restrict__ x, int F, in
     lds_words progl = (lds_words)prog;
     int my_groups = 0;
     auto rendezvous = [&]() {
+#ifndef MSM_COV_NO_RDV
         if constexpr (HALF >= 0) {
             if ((my_groups & 7) == 0) {
                 if (lane == 0) progl[2 * red_wave + HALF] = my_groups;
@@ -161,6 +173,7 @@ __device__ __forceinline__ void cov_wave_body(const T* __restrict__ x, int F, in
             }
             ++my_groups;
         }
+#endif
     };
     int seg = 0;  // wave-uniform
     int64_t q0 = q_begin;
@@ -178,13 +191,16 @@ __device__ __forceinline__ void cov_wave_body(const T* __restrict__ x, int F, in
         // power of two) and scaled back when the wave hands in its tiles: exact, the bits are those of the weighted sum.
         const int64_t len = s_stop - s_start;
         const int64_t o_b = q0 - ft.prefix[seg], o_e = q_hi - ft.prefix[seg];   // wave-uniform group offsets, step 4
-        auto mfma_block = [&](const double (&za)[NT], const double (&zb)[NT], const double (&zy)[NT]) {
+        // M0t tiles take sa (x) sb, M00 tiles za (x) zb; sa = za, sb = zy in the plain flavour, sa = zx + zy in the
+        // symmetric one (upper tiles only)
+        auto mfma_block = [&](const double (&za)[NT], const double (&zb)[NT], const double (&sa)[NT],
+                              const double (&sb)[NT]) {
 #pragma unroll
             for (int a = 0; a < NT; ++a) {
 #pragma unroll
-                for (int b = 0; b < NT; ++b)
+                for (int b = SYM ? a : 0; b < NT; ++b)
                     if (TS::template own_0t<HALF>(a))
-                        acc0t[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(za[a], zy[b], acc0t[a][b], 0, 0, 0);
+                        acc0t[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(sa[a], sb[b], acc0t[a][b], 0, 0, 0);
 #pragma unroll
                 for (int b = a; b < NT; ++b)
                     if (TS::template own_00<HALF>(sym_index<NT>(a, b)))
@@ -201,7 +217,7 @@ __device__ __forceinline__ void cov_wave_body(const T* __restrict__ x, int F, in
             load_group(tt, s_start, s_stop, rx, ry, wx, wy);
             for (int64_t og = oa; og < ob; og += 4) {
                 rendezvous();
-                double za[NT], zb[NT], zy[NT];
+                double za[NT], zb[NT], zy[NT], sv[NT];
                 const double w = fma(ft.wy_w, wy, wx) * inv_w_int;
 #pragma unroll
                 for (int a = 0; a < NT; ++a) {
@@ -217,15 +233,25 @@ __device__ __forceinline__ void cov_wave_body(const T* __restrict__ x, int F, in
                         if (!fok[a]) { cx = 0.0; cy = 0.0; }
                     }
                     za[a] = cx;
-                    zy[a] = wx * cy;
                     zb[a] = w * cx;
-                    if constexpr (HALF <= 0) ssum[a] = fma(wx, cx, ssum[a]);
-                    if constexpr (HALF == 1) ssum[a] = fma(wy, cx, ssum[a]);
-                    if constexpr (HALF < 0) ssum2[a] = fma(wy, cx, ssum2[a]);
+                    if constexpr (SYM) {
+                        sv[a] = cx + cy;
+                        zy[a] = wx * sv[a];
+                        if constexpr (HALF != 0) {
+                            ssum[a] = fma(wx, cx, ssum[a]);
+                            ssum2[a] = fma(wy, cx, ssum2[a]);
+                        }
+                    } else {
+                        sv[a] = cx;
+                        zy[a] = wx * cy;
+                        if constexpr (HALF <= 0) ssum[a] = fma(wx, cx, ssum[a]);
+                        if constexpr (HALF == 1) ssum[a] = fma(wy, cx, ssum[a]);
+                        if constexpr (HALF < 0) ssum2[a] = fma(wy, cx, ssum2[a]);
+                    }
                 }
                 tt += 4;
                 if (og + 4 < ob) load_group(tt, s_start, s_stop, rx, ry, wx, wy);
-                mfma_block(za, zb, zy);
+                mfma_block(za, zb, sv, zy);
             }
         };
         int64_t o_i0 = o_b, o_i1 = o_b;   // interior run [o_i0, o_i1) on the wave's own grid of groups
@@ -238,43 +264,89 @@ __device__ __forceinline__ void cov_wave_body(const T* __restrict__ x, int F, in
         }
         run_general(o_b, o_i0);
         if constexpr (VEC) {
+#ifdef MSM_COV_DEPTH
+            constexpr int kDepth = MSM_COV_DEPTH;
+#else
             constexpr int kDepth = 3;
+#endif
+            // A ring of kDepth groups in flight with a FIXED slot per position in the unrolled trip: no exit and no
+            // conditional load inside the steady loop, so the slots are never copied around and each conversion waits
+            // for its own (oldest) load only.  (With an exit test after every group the compiler rotated the slots
+            // through copies behind s_waitcnt vmcnt(0): the ring was one trip deep whatever kDepth said.)  Rows are
+            // addressed as wave-uniform base + a 32-bit lane offset that never changes: the scalar unit advances the
+            // base, the vector unit does nothing for addresses.
+            const int n_groups = (int)((o_i1 - o_i0) >> 2);
             VT rx[kDepth], ry[kDepth];
-            const T* base = x + s_start * ld + (int64_t)kk * ld + NT * fi_;   // + og * ld per group
-            const int64_t lag_off = (int64_t)lag * ld;
-            auto load_inner = [&](int64_t og, int s) {
-                const T* px = base + og * ld;
-                rx[s] = *reinterpret_cast<const VT*>(px);
-                ry[s] = *reinterpret_cast<const VT*>(px + lag_off);
+            const char* sbase = reinterpret_cast<const char*>(x + (s_start + o_i0) * ld);
+            const uint32_t voff = (uint32_t)(((int64_t)kk * ld + NT * fi_) * (int64_t)sizeof(T));   // host: 4 ld sizeof(T) < 2^31
+            const int64_t step_b = 4 * ld * (int64_t)sizeof(T), lag_b = (int64_t)lag * ld * (int64_t)sizeof(T);
+            auto load_slot = [&](int gi, int s) {
+                const char* p = sbase + gi * step_b;
+                uint32_t off = voff;
+                // opaque: keeps the zero-extension next to the load (scalar base + 32-bit lane offset addressing)
+                asm volatile("" : "+v"(off));
+                rx[s] = *reinterpret_cast<const VT*>(p + off);
+                ry[s] = *reinterpret_cast<const VT*>(p + lag_b + off);
             };
+            auto group = [&](int s, int next, bool more) {
+                rendezvous();
+                double za[NT], zy[NT];
 #pragma unroll
-            for (int s = 0; s < kDepth; ++s)
-                if (o_i0 + 4 * s < o_i1) load_inner(o_i0 + 4 * s, s);
-            for (int64_t og = o_i0; og < o_i1;) {
-#pragma unroll
-                for (int s = 0; s < kDepth; ++s) {
-                    if (og >= o_i1) break;
-                    rendezvous();
-                    double za[NT], zy[NT];
-#pragma unroll
-                    for (int a = 0; a < NT; ++a) {
-                        const double vx = to_f64(rx[s][a]);
-                        const double vy = to_f64(ry[s][a]);
-                        double cx = vx - shift[a];
-                        double cy = vy - shift[a];
-                        if constexpr (!FINITE) {  // NaN -> column mean
-                            if (!(vx == vx)) cx = 0.0;
-                            if (!(vy == vy)) cy = 0.0;
-                        }
-                        za[a] = cx;
+                for (int a = 0; a < NT; ++a) {
+#ifdef MSM_COV_DIAG_NOVALU   // timing experiment only: operands without conversion or centring (wrong results)
+                    if constexpr (sizeof(T) == 4) {
+                        za[a] = __hiloint2double(__float_as_int((float)rx[s][a]), __float_as_int((float)ry[s][(a + 1) % NT]));
+                        zy[a] = __hiloint2double(__float_as_int((float)ry[s][a]), __float_as_int((float)rx[s][(a + 1) % NT]));
+                        continue;
+                    }
+#endif
+                    const double vx = to_f64(rx[s][a]);
+                    const double vy = to_f64(ry[s][a]);
+                    double cx = vx - shift[a];
+                    double cy = vy - shift[a];
+                    if constexpr (!FINITE) {  // NaN -> column mean
+                        if (!(vx == vx)) cx = 0.0;
+                        if (!(vy == vy)) cy = 0.0;
+                    }
+                    za[a] = cx;
+                    if constexpr (SYM) {
+                        zy[a] = cx + cy;
+                        if constexpr (HALF != 0) sint[a] += cx;
+                    } else {
                         zy[a] = cy;
                         ssum[a] += cx;
                         if constexpr (HALF < 0) ssum2[a] += cx;
                     }
-                    if (og + 4 * kDepth < o_i1) load_inner(og + 4 * kDepth, s);
-                    mfma_block(za, za, zy);
-                    og += 4;
                 }
+                // the slot is free only now: a load placed above its conversions lands in other registers and is copied
+                // into the slot behind a full wait.  The empty asm takes every converted value as an input and the
+                // load's lane offset passes through one after it, so the order holds.
+#pragma unroll
+                for (int a = 0; a < NT; ++a) {
+                    if constexpr (!SYM || HALF != 0) asm volatile("" ::"v"(za[a]));
+                    if constexpr (!SYM || HALF <= 0) asm volatile("" ::"v"(zy[a]));
+                }
+#ifndef MSM_COV_DIAG_NOLOAD   // timing experiment only: the ring is never refilled (wrong results)
+                if (more) load_slot(next, s);
+#endif
+                if constexpr (SYM) mfma_block(za, za, zy, zy);
+                else mfma_block(za, za, za, zy);
+            };
+            if (n_groups >= 2 * kDepth) {
+                // (unconditional loads on the way in: with loads under branches ahead of the loop the compiler's
+                // wait-count bookkeeping falls back to "wait for everything" at the loop head)
+#pragma unroll
+                for (int s = 0; s < kDepth; ++s) load_slot(s, s);
+                int g = 0;
+                for (; g + 2 * kDepth <= n_groups; g += kDepth) {
+#pragma unroll
+                    for (int s = 0; s < kDepth; ++s) group(s, g + kDepth + s, true);
+                }
+#pragma unroll
+                for (int i = 0; i < 2 * kDepth - 1; ++i)   // fewer than 2 kDepth groups are left
+                    if (g + i < n_groups) group(i % kDepth, g + i + kDepth, g + i + kDepth < n_groups);
+            } else {
+                run_general(o_i0, o_i1);   // a handful of groups: the weighted path gives the same bits (all weights 1)
             }
         }
         run_general(o_i1, o_e);
@@ -288,9 +360,16 @@ __device__ __forceinline__ void cov_wave_body(const T* __restrict__ x, int F, in
     double* sums = red + S::kTiles * 256;  // [4][2][NT][64]
 #pragma unroll
     for (int a = 0; a < NT; ++a) {
-        if constexpr (HALF <= 0) sums[((red_wave * 2 + 0) * NT + a) * 64 + lane] = ssum[a];
-        if constexpr (HALF == 1) sums[((red_wave * 2 + 1) * NT + a) * 64 + lane] = ssum[a];
-        if constexpr (HALF < 0) sums[((red_wave * 2 + 1) * NT + a) * 64 + lane] = ssum2[a];
+        if constexpr (SYM) {
+            if constexpr (HALF != 0) {
+                sums[((red_wave * 2 + 0) * NT + a) * 64 + lane] = ssum[a] + sint[a];
+                sums[((red_wave * 2 + 1) * NT + a) * 64 + lane] = ssum2[a] + sint[a];
+            }
+        } else {
+            if constexpr (HALF <= 0) sums[((red_wave * 2 + 0) * NT + a) * 64 + lane] = ssum[a];
+            if constexpr (HALF == 1) sums[((red_wave * 2 + 1) * NT + a) * 64 + lane] = ssum[a];
+            if constexpr (HALF < 0) sums[((red_wave * 2 + 1) * NT + a) * 64 + lane] = ssum2[a];
+        }
     }
     for (int w = 0; w < 4; ++w) {
         if (red_wave == w) {
@@ -319,7 +398,7 @@ __device__ __forceinline__ void cov_wave_body(const T* __restrict__ x, int F, in
     }
 }
 
-template <typename T, int NT, bool VEC, bool SPLIT, bool FINITE>
+template <typename T, int NT, bool VEC, bool SPLIT, bool FINITE, bool SYM = false>
 __global__ __launch_bounds__(SPLIT ? 512 : 256, SPLIT ? 2 : 1) void cov_fused_kernel(
     const T* __restrict__ x, int F, int64_t ld, FrameTab ft, const double* __restrict__ mu, int64_t frames_per_wave,
     double* __restrict__ slabs) {
@@ -332,10 +411,10 @@ __global__ __launch_bounds__(SPLIT ? 512 : 256, SPLIT ? 2 : 1) void cov_fused_ke
         __shared__ int prog[8];   // progress of the 4 wave pairs (frame groups done), see cov_wave_body
         if (tid < 8) prog[tid] = 0;
         __syncthreads();
-        if (wave < 4) cov_wave_body<T, NT, VEC, 0, FINITE>(x, F, ld, ft, mu, frames_per_wave, wave, 4, red, wave, prog);
-        else cov_wave_body<T, NT, VEC, 1, FINITE>(x, F, ld, ft, mu, frames_per_wave, wave - 4, 4, red, wave - 4, prog);
+        if (wave < 4) cov_wave_body<T, NT, VEC, 0, FINITE, SYM>(x, F, ld, ft, mu, frames_per_wave, wave, 4, red, wave, prog);
+        else cov_wave_body<T, NT, VEC, 1, FINITE, SYM>(x, F, ld, ft, mu, frames_per_wave, wave - 4, 4, red, wave - 4, prog);
     } else {
-        cov_wave_body<T, NT, VEC, -1, FINITE>(x, F, ld, ft, mu, frames_per_wave, wave, 4, red, wave);
+        cov_wave_body<T, NT, VEC, -1, FINITE, SYM>(x, F, ld, ft, mu, frames_per_wave, wave, 4, red, wave);
     }
     double* slab = slabs + (size_t)blockIdx.x * S::kSlab;
     for (int i = tid; i < S::kTiles * 256; i += blockDim.x) slab[i] = red[i];
@@ -356,21 +435,37 @@ __global__ __launch_bounds__(SPLIT ? 512 : 256, SPLIT ? 2 : 1) void cov_fused_ke
 //   out = [M00 F*F][M0t F*F][sx F][sy F][T]      (raw, centred by `mu`, unscaled)
 // 1024 threads = 16 slab-groups x 64 elements; group g adds slabs g, g+16, ... and the 16
 // partial sums are added in group order (fixed order -> bitwise reproducible).
-template <int NT>
+// SYM: the M0t tile slots hold S (upper tiles): element e of M0t tile (a, b), a <= b, also adds up its M00 partner
+// (same tile position in the symmetric list, same register and lane) and writes (S - M00) / 2 to both mirror places.
+template <int NT, bool SYM = false>
 __global__ __launch_bounds__(1024) void cov_reduce_kernel(const double* __restrict__ slabs, int n_slabs, int F,
                                                          double pairs, double* __restrict__ out) {
     using S = CovShape<NT>;
     __shared__ double red[16][64];
+    __shared__ double red2[SYM ? 16 : 1][64];
     const int io = threadIdx.x & 63, g = threadIdx.x >> 6;
     const int e = blockIdx.x * 64 + io;
-    double part = 0.0;
+    double part = 0.0, part2 = 0.0;
+    int e2 = -1;   // SYM: the M00 element under an S element
+    if constexpr (SYM) {
+        if (e < NT * NT * 256) {
+            const int tile = e >> 8, a = tile / NT, b = tile % NT;
+            if (a <= b) e2 = (NT * NT + sym_index<NT>(a, b)) * 256 + (e & 255);
+        }
+    }
     if (e < S::kSlab)
-        for (int b = g; b < n_slabs; b += 16) part += slabs[(size_t)b * S::kSlab + e];
+        for (int b = g; b < n_slabs; b += 16) {
+            part += slabs[(size_t)b * S::kSlab + e];
+            if (SYM && e2 >= 0) part2 += slabs[(size_t)b * S::kSlab + e2];
+        }
     red[g][io] = part;
+    if constexpr (SYM) red2[g][io] = part2;
     __syncthreads();
     if (g != 0 || e >= S::kSlab) return;
-    double acc = 0.0;
+    double acc = 0.0, acc2 = 0.0;
     for (int k = 0; k < 16; ++k) acc += red[k][io];
+    if constexpr (SYM)
+        for (int k = 0; k < 16; ++k) acc2 += red2[k][io];
     double* M00 = out;
     double* M0t = out + (size_t)F * F;
     double* sxy = M0t + (size_t)F * F;
@@ -383,7 +478,15 @@ __global__ __launch_bounds__(1024) void cov_reduce_kernel(const double* __restri
         // feature of (tile a, row i) is NT*i + a (see cov_fused_kernel)
         if (tile < NT * NT) {
             const int row = NT * row_in + tile / NT, col = NT * col_in + tile % NT;
-            if (row < F && col < F) M0t[(size_t)row * F + col] = acc;
+            if constexpr (SYM) {
+                if (e2 >= 0 && row < F && col < F) {
+                    const double h = 0.5 * (acc - acc2);
+                    M0t[(size_t)row * F + col] = h;
+                    if (tile / NT != tile % NT) M0t[(size_t)col * F + row] = h;
+                }
+            } else {
+                if (row < F && col < F) M0t[(size_t)row * F + col] = acc;
+            }
         } else {
             int s = tile - NT * NT, ti = 0;
             while (s >= NT - ti) { s -= NT - ti; ++ti; }
@@ -642,9 +745,20 @@ msm_status build_frametab(msm_ctx* ctx, int64_t n, const int64_t* h_start, const
     return MSM_OK;
 }
 
+// M0t <- (M0t + M0t') / 2 in place (the symmetric flavour on the shapes without a kernel of their own)
+__global__ __launch_bounds__(256) void symmetrise_m0t_kernel(double* __restrict__ m0t, int F) {
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= (int64_t)F * F) return;
+    const int i = (int)(e / F), j = (int)(e % F);
+    if (i >= j) return;
+    const double h = 0.5 * (m0t[(size_t)i * F + j] + m0t[(size_t)j * F + i]);
+    m0t[(size_t)i * F + j] = h;
+    m0t[(size_t)j * F + i] = h;
+}
+
 template <typename T, int NT>
 msm_status launch_cov(msm_ctx* ctx, const T* x, int F, int64_t ld, const FrameTab& ft, const double* mu,
-                      bool finite, double* d_out) {
+                      bool finite, bool sym, double* d_out) {
     using S = CovShape<NT>;
     int blocks = ctx->n_cu;  // one 4-wave workgroup per CU: each wave owns a SIMD's matrix core
     const int64_t groups = ft.total / kGroup;
@@ -658,29 +772,52 @@ msm_status launch_cov(msm_ctx* ctx, const T* x, int F, int64_t ld, const FrameTa
     if (rs != MSM_OK) return rs;
     const size_t lds = ((size_t)S::kTiles * 256 + (size_t)kWaves * 2 * NT * 64) * sizeof(double);
     // vector path: every lane's NT features exist and its NT-element load is aligned
-    const bool vec = (NT != 3) && (F == 16 * NT) && (ld % NT == 0) && (((uintptr_t)x) % (NT * sizeof(T)) == 0);
+    const bool vec = (NT != 3) && (F == 16 * NT) && (ld % NT == 0) && (((uintptr_t)x) % (NT * sizeof(T)) == 0) &&
+                     (ld * 4 * (int64_t)sizeof(T) < (int64_t(1) << 31));   // the kernel's 32-bit lane offsets
     constexpr bool kSplit = NT >= 3;
+    constexpr bool kHasSym = kSplit;   // the symmetric flavour pays where the tiles are split over a wave pair
     auto kern = vec ? (finite ? cov_fused_kernel<T, NT, true, kSplit, true> : cov_fused_kernel<T, NT, true, kSplit, false>)
                     : (finite ? cov_fused_kernel<T, NT, false, kSplit, true> : cov_fused_kernel<T, NT, false, kSplit, false>);
+    if constexpr (kHasSym) {
+        if (sym)
+            kern = vec ? (finite ? cov_fused_kernel<T, NT, true, kSplit, true, true> : cov_fused_kernel<T, NT, true, kSplit, false, true>)
+                       : (finite ? cov_fused_kernel<T, NT, false, kSplit, true, true> : cov_fused_kernel<T, NT, false, kSplit, false, true>);
+    }
     if (lds > 48 * 1024)
         MSM_HIP(ctx, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(kern, dim3(blocks), dim3(kSplit ? 512 : 256), lds, ctx->stream, x, F, ld, ft, mu, fpw,
                        (double*)ctx->scratch);
     MSM_CHECK_LAUNCH(ctx);
-    hipLaunchKernelGGL(cov_reduce_kernel<NT>, dim3(msm_ceil_div(S::kSlab, 64)), dim3(1024), 0, ctx->stream,
-                       (const double*)ctx->scratch, blocks, F, (double)ft.pairs, d_out);
+    if (sym && kHasSym) {
+        hipLaunchKernelGGL((cov_reduce_kernel<NT, kHasSym>), dim3(msm_ceil_div(S::kSlab, 64)), dim3(1024), 0, ctx->stream,
+                           (const double*)ctx->scratch, blocks, F, (double)ft.pairs, d_out);
+    } else {
+        hipLaunchKernelGGL(cov_reduce_kernel<NT>, dim3(msm_ceil_div(S::kSlab, 64)), dim3(1024), 0, ctx->stream,
+                           (const double*)ctx->scratch, blocks, F, (double)ft.pairs, d_out);
+        if (sym) {
+            MSM_CHECK_LAUNCH(ctx);
+            hipLaunchKernelGGL(symmetrise_m0t_kernel, dim3(msm_ceil_div(F * F, 256)), dim3(256), 0, ctx->stream,
+                               d_out + (size_t)F * F, F);
+        }
+    }
     MSM_CHECK_LAUNCH(ctx);
     return MSM_OK;
 }
 
 template <typename T>
 msm_status dispatch_cov(msm_ctx* ctx, const T* x, int F, int64_t ld, const FrameTab& ft, const double* mu,
-                        bool finite, double* d_out) {
-    if (F <= 16) return launch_cov<T, 1>(ctx, x, F, ld, ft, mu, finite, d_out);
-    if (F <= 32) return launch_cov<T, 2>(ctx, x, F, ld, ft, mu, finite, d_out);
-    if (F <= 48) return launch_cov<T, 3>(ctx, x, F, ld, ft, mu, finite, d_out);
-    if (F <= 64) return launch_cov<T, 4>(ctx, x, F, ld, ft, mu, finite, d_out);
-    return launch_cov_blocked<T>(ctx, x, F, ld, ft, mu, finite, d_out);
+                        bool finite, bool sym, double* d_out) {
+    if (F <= 16) return launch_cov<T, 1>(ctx, x, F, ld, ft, mu, finite, sym, d_out);
+    if (F <= 32) return launch_cov<T, 2>(ctx, x, F, ld, ft, mu, finite, sym, d_out);
+    if (F <= 48) return launch_cov<T, 3>(ctx, x, F, ld, ft, mu, finite, sym, d_out);
+    if (F <= 64) return launch_cov<T, 4>(ctx, x, F, ld, ft, mu, finite, sym, d_out);
+    msm_status rs = launch_cov_blocked<T>(ctx, x, F, ld, ft, mu, finite, d_out);
+    if (rs == MSM_OK && sym) {
+        hipLaunchKernelGGL(symmetrise_m0t_kernel, dim3(msm_ceil_div((int64_t)F * F, 256)), dim3(256), 0, ctx->stream,
+                           d_out + (size_t)F * F, F);
+        MSM_CHECK_LAUNCH(ctx);
+    }
+    return rs;
 }
 
 }  // namespace
@@ -734,7 +871,8 @@ extern "C" {
 
 static msm_status lagged_moments_impl(msm_ctx* ctx, const void* d_x, msm_dtype dtype, int64_t n, int F, int64_t ld,
                                       const int64_t* h_seg_start, const int64_t* h_seg_stop, int n_seg, int lag,
-                                      const double* d_shift, int assume_finite, bool one_sided, double* d_moments) {
+                                      const double* d_shift, int assume_finite, bool one_sided, bool sym,
+                                      double* d_moments) {
     if (!ctx) return MSM_ERR_INVALID;
     MSM_REQUIRE(ctx, n >= 0 && F >= 1 && ld >= F, "msm_lagged_moments: need n >= 0, F >= 1, ld >= F");
     MSM_REQUIRE(ctx, dtype == MSM_F32 || dtype == MSM_F64, "msm_lagged_moments: bad dtype");
@@ -747,22 +885,29 @@ static msm_status lagged_moments_impl(msm_ctx* ctx, const void* d_x, msm_dtype d
         return MSM_OK;
     }
     if (dtype == MSM_F32)
-        return dispatch_cov<float>(ctx, (const float*)d_x, F, ld, ft, d_shift, assume_finite != 0, d_moments);
-    return dispatch_cov<double>(ctx, (const double*)d_x, F, ld, ft, d_shift, assume_finite != 0, d_moments);
+        return dispatch_cov<float>(ctx, (const float*)d_x, F, ld, ft, d_shift, assume_finite != 0, sym, d_moments);
+    return dispatch_cov<double>(ctx, (const double*)d_x, F, ld, ft, d_shift, assume_finite != 0, sym, d_moments);
 }
 
 msm_status msm_lagged_moments(msm_ctx* ctx, const void* d_x, msm_dtype dtype, int64_t n, int F, int64_t ld,
                               const int64_t* h_seg_start, const int64_t* h_seg_stop, int n_seg, int lag,
                               const double* d_shift, int assume_finite, double* d_moments) {
     return lagged_moments_impl(ctx, d_x, dtype, n, F, ld, h_seg_start, h_seg_stop, n_seg, lag, d_shift, assume_finite,
-                               false, d_moments);
+                               false, false, d_moments);
+}
+
+msm_status msm_lagged_moments_reversible(msm_ctx* ctx, const void* d_x, msm_dtype dtype, int64_t n, int F, int64_t ld,
+                                         const int64_t* h_seg_start, const int64_t* h_seg_stop, int n_seg, int lag,
+                                         const double* d_shift, int assume_finite, double* d_moments) {
+    return lagged_moments_impl(ctx, d_x, dtype, n, F, ld, h_seg_start, h_seg_stop, n_seg, lag, d_shift, assume_finite,
+                               false, true, d_moments);
 }
 
 msm_status msm_lagged_moments_onesided(msm_ctx* ctx, const void* d_x, msm_dtype dtype, int64_t n, int F, int64_t ld,
                                        const int64_t* h_seg_start, const int64_t* h_seg_stop, int n_seg, int lag,
                                        const double* d_shift, int assume_finite, double* d_moments) {
     return lagged_moments_impl(ctx, d_x, dtype, n, F, ld, h_seg_start, h_seg_stop, n_seg, lag, d_shift, assume_finite,
-                               true, d_moments);
+                               true, false, d_moments);
 }
 
 msm_status msm_moments_from_lagged(msm_ctx* ctx, const void* d_x, msm_dtype dtype, int64_t n, int F, int64_t ld,

@@ -421,15 +421,19 @@ class Engine:
 
     def lagged_moments(self, x: DeviceArray, lag: int, shift: DeviceArray, *, starts=None, stops=None,
                        assume_finite: bool = False, out: DeviceArray | None = None,
-                       one_sided: bool = False) -> DeviceArray:
+                       one_sided: bool = False, symmetric: bool = False) -> DeviceArray:
         """Raw lagged moments [M00 | M0t | sx | sy | T] (2F^2+2F+1 f64): the reversible estimator's
-        (M00 over X0 and Yt) or, with one_sided, M00 over X0 only."""
+        (M00 over X0 and Yt) or, with one_sided, M00 over X0 only.  symmetric: the M0t block holds
+        (M0t + M0t') / 2 -- all a reversible TICA reads of it -- from the cheaper symmetric accumulation."""
+        if one_sided and symmetric:
+            raise ValueError("one_sided and symmetric moments exclude each other")
         n, F = x.shape
         if starts is None:
             starts, stops = segments_to_bounds(None, n)
         starts, stops = self._seg_ptrs(starts, stops)
         out = out if out is not None else self.empty((2 * F * F + 2 * F + 1,), np.float64)
-        fn = lib.msm_lagged_moments_onesided if one_sided else lib.msm_lagged_moments
+        fn = (lib.msm_lagged_moments_onesided if one_sided
+              else lib.msm_lagged_moments_reversible if symmetric else lib.msm_lagged_moments)
         check(fn(self.handle, x.ptr, _dtype_code(x.dtype), n, F, F, starts.ctypes.data, stops.ctypes.data, len(starts),
                  int(lag), shift.ptr, int(bool(assume_finite)), out.ptr), self.handle)
         return out

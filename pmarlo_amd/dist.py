@@ -339,7 +339,7 @@ class ShardedMSM:
         if cfg.tica_dim > 0:
             # 1. time-lagged raw moments about the shared shift (fp64 MFMA): the only pass over X before the
             #    projection -- the standardisation sums follow from them and 2 * lag edge frames
-            eng.lagged_moments(self.x, cfg.lag, b["shift"], assume_finite=True, out=b["lagged"])
+            eng.lagged_moments(self.x, cfg.lag, b["shift"], assume_finite=True, out=b["lagged"], symmetric=True)
             eng.moments_from_lagged(self.x, cfg.lag, b["shift"], b["lagged"], out=b["mom_sums"])
             if multi:
                 comm.allreduce_sum("moments")

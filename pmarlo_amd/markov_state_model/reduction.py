@@ -67,7 +67,7 @@ def pca_reduce(X: np.ndarray, n_components: int = 2, batch_size: Optional[int] =
     pipe = MSMPipeline(eng)
     xd = eng.to_device(Xm)
     mu, sigma, inv_sigma, has_nan = pipe.standardise_params(xd, scale=scale)
-    mom = pipe.tica_moments(xd, 0, mu, assume_finite=not has_nan).to_host()
+    mom = pipe.tica_moments(xd, 0, mu, assume_finite=not has_nan, symmetric=True).to_host()
     sd = sigma.to_host()
     S = 0.5 * mom[:F * F].reshape(F, F)                      # sum (x - mu)(x - mu)'
     delta = mom[2 * F * F:2 * F * F + F] / float(n)          # residual mean of the centred data (~1e-17)
@@ -181,7 +181,7 @@ def tica_fit_transform_trajectories(features: np.ndarray, traj_lengths: Sequence
     # deeptime removes the data mean itself; no scaling: sigma = 1
     mu, _, _, has_nan = pipe.standardise_params(xd, scale=False)
     one = eng.to_device(np.ones(Xm.shape[1]))
-    mom = pipe.tica_moments(xd, lag, mu, segments=segs, assume_finite=not has_nan)
+    mom = pipe.tica_moments(xd, lag, mu, segments=segs, assume_finite=not has_nan, symmetric=True)
     model = pipe.tica_solve(mom, mu, one, one, lag, n_components)
     model.dim = min(n_components, int(model.rank.to_host()[0]))
     Y = pipe.tica_transform(model, xd).to_host()

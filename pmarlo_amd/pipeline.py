@@ -83,22 +83,25 @@ class MSMPipeline:
 
     # ---- TICA ------------------------------------------------------------------
     def tica_moments(self, x: DeviceArray, lag: int, mu: DeviceArray, segments=None, assume_finite=False,
-                     out: DeviceArray | None = None) -> DeviceArray:
+                     out: DeviceArray | None = None, symmetric: bool = False) -> DeviceArray:
+        """Raw lagged moments over the segments; symmetric: M0t comes back as (M0t + M0t') / 2 from the cheaper
+        symmetric accumulation (what a reversible TICA or a PCA needs; VAMP needs the plain block)."""
         starts, stops = segments_to_bounds(segments, x.shape[0])
         if len(starts) <= 16:
-            return self.eng.lagged_moments(x, lag, mu, starts=starts, stops=stops, assume_finite=assume_finite, out=out)
+            return self.eng.lagged_moments(x, lag, mu, starts=starts, stops=stops, assume_finite=assume_finite, out=out,
+                                           symmetric=symmetric)
         # more than 16 trajectories: accumulate the (additive) raw moments in chunks
         total = None
         for i in range(0, len(starts), 16):
             part = self.eng.lagged_moments(x, lag, mu, starts=starts[i:i + 16], stops=stops[i:i + 16],
-                                           assume_finite=assume_finite).to_host()
+                                           assume_finite=assume_finite, symmetric=symmetric).to_host()
             total = part if total is None else total + part
         return self.eng.to_device(total) if out is None else out.copy_from_host(total)
 
     def tica_fit(self, x: DeviceArray, lag: int, dim: int, *, scale: bool = True, segments=None,
                  epsilon: float = 1e-6, kinetic_map: bool = True) -> TicaModel:
         mu, sigma, inv_sigma, has_nan = self.standardise_params(x, scale=scale)
-        mom = self.tica_moments(x, lag, mu, segments=segments, assume_finite=not has_nan)
+        mom = self.tica_moments(x, lag, mu, segments=segments, assume_finite=not has_nan, symmetric=True)
         return self.tica_solve(mom, mu, sigma, inv_sigma, lag, dim, epsilon=epsilon, kinetic_map=kinetic_map)
 
     def tica_solve(self, moments: DeviceArray, mu, sigma, inv_sigma, lag: int, dim: int, *, epsilon: float = 1e-6,

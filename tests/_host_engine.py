@@ -81,10 +81,11 @@ class HostEngine:
         first = X[0].copy() if shift is None else shift.a
         return None, HostArray(np.array(first))
 
-    def lagged_moments(self, x, lag, shift, *, assume_finite=False, out=None, **_):
+    def lagged_moments(self, x, lag, shift, *, assume_finite=False, out=None, symmetric=False, **_):
         F = x.shape[1]
         m = npport.lagged_moments([x.a.astype(np.float64) - shift.a], lag)
-        out.a[...] = np.concatenate([m["Mxx"].ravel(), m["Mxy_half"].ravel(), m["sx"], m["sy"], [float(m["T"])]])
+        mxy = 0.5 * (m["Mxy_half"] + m["Mxy_half"].T) if symmetric else m["Mxy_half"]
+        out.a[...] = np.concatenate([m["Mxx"].ravel(), mxy.ravel(), m["sx"], m["sy"], [float(m["T"])]])
         return out
 
     def moments_from_lagged(self, x, lag, shift, moments, *, out=None, **_):

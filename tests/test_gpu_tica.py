@@ -86,6 +86,44 @@ def test_lagged_moments_vs_oracle(engine, n, F, lag, dtype, segs):
     np.testing.assert_allclose(sx, want["sx"], rtol=0, atol=1e-13 * sum_abs)
     np.testing.assert_allclose(sy, want["sy"], rtol=0, atol=1e-13 * sum_abs)
     np.testing.assert_array_equal(M00, M00.T)
+    # the symmetric flavour (S = sum (zx + zy)(zx + zy)' and M00, then (S - M00) / 2 on 32 < F <= 64): same M00 and
+    # sums, the M0t block symmetrised; S carries up to 4x the magnitude, hence the wider bound
+    sym = engine.lagged_moments(xd, lag, engine.to_device(shift), symmetric=True, **kw).to_host()
+    sym_fin = engine.lagged_moments(xd, lag, engine.to_device(shift), symmetric=True, assume_finite=True, **kw).to_host()
+    np.testing.assert_array_equal(sym, sym_fin)
+    S00, S0t = sym[:F * F].reshape(F, F), sym[F * F:2 * F * F].reshape(F, F)
+    np.testing.assert_allclose(S00, want["Mxx"], rtol=0, atol=1e-12 * scale)
+    np.testing.assert_allclose(S0t, 0.5 * (want["Mxy_half"] + want["Mxy_half"].T), rtol=0, atol=4e-12 * scale)
+    np.testing.assert_array_equal(S0t, S0t.T)
+    np.testing.assert_array_equal(S00, S00.T)
+    np.testing.assert_allclose(sym[2 * F * F:2 * F * F + F], want["sx"], rtol=0, atol=1e-13 * sum_abs)
+    np.testing.assert_allclose(sym[2 * F * F + F:2 * F * F + 2 * F], want["sy"], rtol=0, atol=1e-13 * sum_abs)
+    assert sym[-1] == want["T"]
+
+
+def test_lagged_moments_symmetric_exact_integers(engine):
+    """Integer data: S, M00 and their difference are exact, so the symmetric flavour must reproduce (M0t + M0t') / 2 bit
+    for bit on every kernel shape (F = 48 and 64: symmetric tiles; 20: plain pass + in-place symmetrisation; 80: blocked)."""
+    rng = np.random.default_rng(5)
+    for n, F, lag, dtype in [(1031, 64, 3, np.float32), (517, 48, 2, np.float64), (300, 20, 1, np.float32),
+                             (400, 80, 4, np.float64)]:
+        X = rng.integers(-3, 4, size=(n, F)).astype(dtype)
+        X[:, 1] = np.arange(n) % 5
+        segs = [(0, n // 3), (n // 3, n)]
+        starts, stops = _bounds(segs)
+        mom = engine.lagged_moments(engine.to_device(X), lag, engine.zeros((F,), np.float64), symmetric=True,
+                                    starts=starts, stops=stops).to_host()
+        want = npport.lagged_moments([X[a:b].astype(np.float64) for a, b in segs], lag)
+        np.testing.assert_array_equal(mom[:F * F].reshape(F, F), want["Mxx"])
+        np.testing.assert_array_equal(mom[F * F:2 * F * F].reshape(F, F), 0.5 * (want["Mxy_half"] + want["Mxy_half"].T))
+        np.testing.assert_array_equal(mom[2 * F * F:2 * F * F + F], want["sx"])
+        np.testing.assert_array_equal(mom[2 * F * F + F:2 * F * F + 2 * F], want["sy"])
+    # lag 0 (the PCA covariance): M00 = 2 X'X, M0t = X'X
+    X = rng.integers(-3, 4, size=(200, 64)).astype(np.float32)
+    mom = engine.lagged_moments(engine.to_device(X), 0, engine.zeros((64,), np.float64), symmetric=True).to_host()
+    G = X.astype(np.float64).T @ X.astype(np.float64)
+    np.testing.assert_array_equal(mom[:64 * 64].reshape(64, 64), 2.0 * G)
+    np.testing.assert_array_equal(mom[64 * 64:2 * 64 * 64].reshape(64, 64), G)
 
 
 def test_lagged_moments_mfma_layout_asymmetric(engine):
