@@ -528,9 +528,13 @@ struct TriShared {
     double scale, gl, gu;
     double red[kEigThreads / 64];
     int bad;
-    double part[8][kTriMax];   // partial products of the tridiagonalisation, one row per working wave
-    double2 vw[8][kTriMax];    // {v_j, w_j} of the column in flight, one copy per working wave
-    alignas(16) double lv[12][kTriMax];    // multipliers of the LDL' column in flight, one copy per working wave
+    double part[16][kTriMax];  // partial products of the tridiagonalisation, one row per wave (the LDL' phase uses rows 0-7)
+    union {                    // the two register-resident phases never overlap
+        double2 vw[8][kTriMax];                 // tridiagonalisation: {v_j, w_j} of the column in flight, one copy per A wave
+        alignas(16) double lv[12][kTriMax];     // LDL': multipliers of the column in flight, one copy per working wave
+    };
+    double vpub[2][kTriMax];   // tridiagonalisation: the reflector of column k for the Q' waves, slot k & 1
+    double taupub[2];
 };
 
 typedef double tri_v4f64 __attribute__((ext_vector_type(4)));
@@ -635,22 +639,26 @@ __device__ __forceinline__ int sturm_count(const TriShared* ts, int nblocks, dou
     return (int)(cnt + __popc(bits));
 }
 
-// Tridiagonalisation A = Q T Q' with the matrices held in REGISTERS, every wave of the workgroup in lockstep, two
+// Tridiagonalisation A = Q T Q' with the matrices held in REGISTERS, every wave of the workgroup at work, two
 // barriers per column.
-// Measured on this chip (tools/probe/lone_wave_lds_probe.hip, tri_probe.hip): a wave alone on its CU runs at about one
-// instruction per 10 cycles whatever the instruction (instruction fetch has nobody to hide behind), pays ~37 cycles
-// per taken branch and 12-19 per LDS instruction, so one barrier-free wave sweeping an LDS-resident matrix needed
-// ~5000 cycles per column; sixteen waves sweeping it between barriers were no faster.  Here nothing is swept:
-//   waves 0-3 hold the rows j = w (mod 4) of A for the whole reduction, waves 4-7 the same rows of Q'
-//   (QT[j][r] = Q[r][j]): 16 doubles per lane, indexed by compile-time constants only (lane = column); waves 8.. only
-//   keep the barriers company;
-//   (1) every working wave reads row k (written to the LDS by its owner one column earlier) and forms the reflector
-//       itself (same inputs, same instructions, same bits): x = A[k][k+1:], H = I - tau v v', v_{k+1} = 1;
-//   (2) partial products over the own rows: p = A22 v (A side), u = Q v (Q side); the v_j come back as broadcast reads
-//       of the wave's own LDS copy of v; one LDS row of partials per wave; barrier;
-//   (3) the four partials are summed in a fixed order by everybody who needs them; A side: w = tau p - (tau^2 p.v / 2) v
-//       and a_j -= v_j w + w_j v on the own rows, the owner of row k + 1 leaving it in the LDS; Q side: q_j -= tau v_j u;
-//       barrier.
+// Measured on this chip (tools/probe/lone_wave_lds_probe.hip, tri_probe.hip): a wave issues about one instruction per
+// 10 cycles whatever the instruction and however many waves share its SIMD (a SIMD takes one per ~4 cycles between
+// all its waves), pays ~37 cycles per taken branch and 12-19 per LDS instruction, so one barrier-free wave sweeping an
+// LDS-resident matrix needed ~5000 cycles per column and sixteen waves sweeping it between barriers were no faster.
+// Here nothing is swept and the per-wave instruction chain of a column is kept short:
+//   waves 0-7 hold the rows j = w (mod 8) of A for the whole reduction, waves 8-15 the same rows of Q'
+//   (QT[j][r] = Q[r][j]): 8 doubles per lane, indexed by compile-time constants only (lane = column);
+//   A waves, column k:
+//   (1) read row k (left in the LDS by its owner one column earlier) and form the reflector, every A wave for itself
+//       (same inputs, same instructions, same bits): x = A[k][k+1:], H = I - tau v v', v_{k+1} = 1; wave 0 also leaves
+//       v and tau in the LDS for the Q' waves;
+//   (2) partial product p = A22 v over the own rows (the v_j come back as broadcast reads of the wave's own LDS copy);
+//       barrier 1;
+//   (3) the eight partials are summed in a fixed order, w = tau p - (tau^2 p.v / 2) v, a_j -= v_j w + w_j v on the own
+//       rows, the owner of row k + 1 leaving it in the LDS; barrier 2.
+//   Q' waves run half a column behind and never form a reflector: between barrier 1 and 2 of column k they read v_k and
+//   write their partial u = Q v; between barrier 2 and barrier 1 of the next column they sum the partials and apply
+//   q_j -= tau v_j u.  They add nothing to the A waves' chain, which is what a column costs.
 // Rows up to k carry v_j = w_j = 0; groups of four own rows that lie entirely there are skipped.
 __device__ __forceinline__ double bcast_lane(double x, int j) {   // lane j's value to everybody; j uniform
     const long long b = __double_as_longlong(x);
@@ -659,38 +667,73 @@ __device__ __forceinline__ double bcast_lane(double x, int j) {   // lane j's va
 }
 template <typename F>
 __device__ __forceinline__ void hh_for_groups(int sub, int k, F&& body) {
-    // own rows sub + 4 t, t = 4 g + u; group g is dead once its last row sub + 16 g + 12 <= k
+    // own rows sub + 8 t, t = 4 g + u; group g is dead once its last row sub + 32 g + 24 <= k
 #pragma unroll
-    for (int g = 0; g < 4; ++g)
-        if (sub + 16 * g + 12 > k) body(g);
+    for (int g = 0; g < 2; ++g)
+        if (sub + 32 * g + 24 > k) body(g);
 }
 __device__ __forceinline__ void householder_phase(double* A, double* QT, int n, TriShared* ts) {
+    static_assert(kEigThreads == 1024, "householder_phase deals the rows of A and Q' over sixteen waves");
     constexpr int ld = kTriLd;
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const bool in = lane < n;
+    const bool is_a = wave < 8;
 #ifdef MSM_TRI_NOQ   // diagnostic build only (tools/probe/tri_probe.hip): what the tridiagonalisation costs without its Q waves
-    const int role = wave < 4 ? 0 : 2;
+    const bool is_q = false;
 #else
-    const int role = wave < 4 ? 0 : (wave < 8 ? 1 : 2);
+    const bool is_q = !is_a;
 #endif
-    const int sub = wave & 3;
-    double* part = ts->part[(role == 1 ? 4 : 0) + sub];
-    const double* parts = ts->part[role == 1 ? 4 : 0];
-    double2* vw = ts->vw[wave & 7];   // this wave's own copy of {v_j, w_j}
-    double m[16];                     // rows sub + 4 t of A (role 0) or Q' (role 1), column `lane`
-    if (role < 2) {
+    const int sub = wave & 7;
+    double* part = ts->part[wave];
+    const double* parts = ts->part[is_a ? 0 : 8];
+    double2* vw = ts->vw[sub];        // A waves: this wave's own copy of {v_j, w_j}
+    double m[8];                      // rows sub + 8 t of A or Q', column `lane`
 #pragma unroll
-        for (int t = 0; t < 16; ++t) {
-            const int j = sub + 4 * t;
-            m[t] = (in && j < n) ? (role == 0 ? A[j * ld + lane] : (j == lane ? 1.0 : 0.0)) : 0.0;
-        }
+    for (int t = 0; t < 8; ++t) {
+        const int j = sub + 8 * t;
+        m[t] = (in && j < n) ? (is_a ? A[j * ld + lane] : (j == lane ? 1.0 : 0.0)) : 0.0;
     }
+    // Q' side of column c: partial u = Q v over the own rows / sum of the partials and the update
+    auto q_partial = [&](int c) {
+        if (__builtin_amdgcn_readfirstlane(ts->taupub[c & 1] != 0.0)) {
+            const double* vp = ts->vpub[c & 1];
+            double s0 = 0.0, s1 = 0.0;
+            hh_for_groups(sub, c, [&](int g) {
+                double v[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) v[u] = vp[sub + 32 * g + 8 * u];
+                s0 = fma(m[4 * g], v[0], s0);
+                s1 = fma(m[4 * g + 1], v[1], s1);
+                s0 = fma(m[4 * g + 2], v[2], s0);
+                s1 = fma(m[4 * g + 3], v[3], s1);
+            });
+            part[lane] = s0 + s1;
+        }
+    };
+    auto sum_parts = [&]() {
+        return (((parts[lane] + parts[kTriMax + lane]) + (parts[2 * kTriMax + lane] + parts[3 * kTriMax + lane])) +
+                ((parts[4 * kTriMax + lane] + parts[5 * kTriMax + lane]) + (parts[6 * kTriMax + lane] + parts[7 * kTriMax + lane])));
+    };
+    auto q_finish = [&](int c) {
+        const double tau_c = ts->taupub[c & 1];
+        if (__builtin_amdgcn_readfirstlane(tau_c != 0.0)) {
+            const double* vp = ts->vpub[c & 1];
+            const double tu = -tau_c * sum_parts();
+            hh_for_groups(sub, c, [&](int g) {
+                double v[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) v[u] = vp[sub + 32 * g + 8 * u];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) m[4 * g + u] = fma(tu, v[u], m[4 * g + u]);
+            });
+        }
+    };
     LSTAMP_INIT
     for (int k = 0; k + 2 < n; ++k) {
         LSTAMP(16);
         double vi = 0.0, tau = 0.0;
         const bool act = in && lane > k;
-        if (role < 2) {
+        if (is_a) {
             const double* rowk = A + k * ld;
             double xi = rowk[in ? lane : 0];
             const double alpha = rowk[k + 1];
@@ -706,7 +749,10 @@ __device__ __forceinline__ void householder_phase(double* A, double* QT, int n, 
                 scal = nr_rcp(alpha - beta);
             }
             vi = act ? (lane == k + 1 ? 1.0 : xi * scal) : 0.0;
-            if (wave == 0 && lane == 0) ts->e[k] = beta;
+            if (wave == 0) {
+                ts->vpub[k & 1][lane] = vi;
+                if (lane == 0) { ts->e[k] = beta; ts->taupub[k & 1] = tau; }
+            }
             LSTAMP(17);
             if (__builtin_amdgcn_readfirstlane(tau != 0.0)) {
                 vw[lane].x = vi;
@@ -714,7 +760,7 @@ __device__ __forceinline__ void householder_phase(double* A, double* QT, int n, 
                 hh_for_groups(sub, k, [&](int g) {
                     double v[4];
 #pragma unroll
-                    for (int u = 0; u < 4; ++u) v[u] = vw[sub + 16 * g + 4 * u].x;
+                    for (int u = 0; u < 4; ++u) v[u] = vw[sub + 32 * g + 8 * u].x;
                     s0 = fma(m[4 * g], v[0], s0);
                     s1 = fma(m[4 * g + 1], v[1], s1);
                     s0 = fma(m[4 * g + 2], v[2], s0);
@@ -723,12 +769,14 @@ __device__ __forceinline__ void householder_phase(double* A, double* QT, int n, 
                 part[lane] = s0 + s1;
             }
             LSTAMP(18);
+        } else if (is_q && k > 0) {
+            q_finish(k - 1);
         }
         __syncthreads();
         LSTAMP(19);
-        if (role < 2 && __builtin_amdgcn_readfirstlane(tau != 0.0)) {
-            const double p = ((parts[lane] + parts[kTriMax + lane]) + parts[2 * kTriMax + lane]) + parts[3 * kTriMax + lane];
-            if (role == 0) {
+        if (is_a) {
+            if (__builtin_amdgcn_readfirstlane(tau != 0.0)) {
+                const double p = sum_parts();
                 const double pv = wave_sum_all(act ? p * vi : 0.0);
                 const double al = -0.5 * tau * (tau * pv);
                 const double wi = act ? fma(tau, p, al * vi) : 0.0;
@@ -737,37 +785,31 @@ __device__ __forceinline__ void householder_phase(double* A, double* QT, int n, 
                 hh_for_groups(sub, k, [&](int g) {
                     double2 b[4];
 #pragma unroll
-                    for (int u = 0; u < 4; ++u) b[u] = vw[sub + 16 * g + 4 * u];
+                    for (int u = 0; u < 4; ++u) b[u] = vw[sub + 32 * g + 8 * u];
 #pragma unroll
                     for (int u = 0; u < 4; ++u) {
                         m[4 * g + u] = fma(-wi, b[u].x, fma(-vi, b[u].y, m[4 * g + u]));
-                        if (in && sub + 16 * g + 4 * u == k + 1) A[(k + 1) * ld + lane] = m[4 * g + u];   // next column's x
+                        if (in && sub + 32 * g + 8 * u == k + 1) A[(k + 1) * ld + lane] = m[4 * g + u];   // next column's x
                     }
                 });
-            } else {
-                const double tu = -tau * p;
-                hh_for_groups(sub, k, [&](int g) {
-                    double v[4];
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) v[u] = vw[sub + 16 * g + 4 * u].x;
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) m[4 * g + u] = fma(tu, v[u], m[4 * g + u]);
-                });
             }
+        } else if (is_q) {
+            q_partial(k);
         }
         LSTAMP(21);
         __syncthreads();
     }
+    if (is_q && n > 2) q_finish(n - 3);
     // back to the LDS: Q' whole, of A the last two rows (the 2 x 2 block the reduction leaves)
-    if (role == 1 && in) {
+    if (is_q && in) {
 #pragma unroll
-        for (int t = 0; t < 16; ++t)
-            if (sub + 4 * t < n) QT[(sub + 4 * t) * ld + lane] = m[t];
+        for (int t = 0; t < 8; ++t)
+            if (sub + 8 * t < n) QT[(sub + 8 * t) * ld + lane] = m[t];
     }
-    if (role == 0 && in) {
+    if (is_a && in) {
 #pragma unroll
-        for (int t = 0; t < 16; ++t)
-            if (sub + 4 * t >= n - 2 && sub + 4 * t < n) A[(sub + 4 * t) * ld + lane] = m[t];
+        for (int t = 0; t < 8; ++t)
+            if (sub + 8 * t >= n - 2 && sub + 8 * t < n) A[(sub + 8 * t) * ld + lane] = m[t];
     }
     __syncthreads();
     if (threadIdx.x == 0) {

@@ -72,6 +72,13 @@ __device__ __forceinline__ int filter_part_x(int t) { return t == 2 || t == 3 ? 
 // when `a` is already the result of a VALU maximum, which is why the pair maximum below starts from b2.
 __device__ __forceinline__ float max3_f32(float a, float b, float c) { return __builtin_fmaxf(__builtin_fmaxf(a, b), c); }
 __device__ __forceinline__ float med3_f32(float a, float b, float c) { return __builtin_amdgcn_fmed3f(a, b, c); }
+// the bare v_max_f32 (operands are never NaN where this is used): fmaxf() on a loop-carried value costs an extra
+// canonicalising v_max per call, and med3(a, b, +inf) is folded back into it
+__device__ __forceinline__ float hw_max_f32(float a, float b) {
+    float r;
+    asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
 
 // ---------------------------------------------------------------------------------------------------------
 // Frame images: row t = the B operand of frame t, 32 * NM bf16 slots in slot order (lane (j, q) of instruction m
@@ -339,9 +346,9 @@ __global__ __launch_bounds__(1024, 4) void kmeans_filter_kernel(
         }
         return a - crow[DP];
     };
-    auto load_frame = [&](int64_t t, double (&z)[DP]) {
+    auto load_frame = [&](int64_t t, double (&z)[DP], auto vec_tag) {
         const T* row = x + t * ld;
-        if (vec_rows) {
+        if constexpr (decltype(vec_tag)::value) {
             const double2* r2 = reinterpret_cast<const double2*>(row);
 #pragma unroll
             for (int f2 = 0; f2 < DP / 2; ++f2) {
@@ -428,7 +435,7 @@ __global__ __launch_bounds__(1024, 4) void kmeans_filter_kernel(
                 m = max3_f32(m, accb[u][2], accb[u][3]);
                 const bool better = m > b1[u];
                 b2[u] = med3_f32(b1[u], b2[u], m);
-                b1[u] = __builtin_fmaxf(b1[u], m);
+                b1[u] = hw_max_f32(b1[u], m);
                 bp[u] = better ? jt : bp[u];
             }
         }
@@ -452,8 +459,18 @@ __global__ __launch_bounds__(1024, 4) void kmeans_filter_kernel(
         // ---- refinement, frame group by frame group; the coordinates of the next group are in flight meanwhile.
         // The loop is NOT unrolled (one copy of this long body keeps the scalar registers in hand): the per-group
         // values rotate through slot 0 instead.
+        // (one copy of the loop per row-load flavour: with the flavour chosen inside, the two load sequences met in
+        // front of the scoring chain and the wait counts there fell back to draining the loads just issued for the
+        // NEXT group -- the prefetch hid nothing)
+        auto refine_unit = [&](auto vec_tag) {
+        // delta mode: the previous label of a frame is fetched one group ahead too, and BEFORE that group's
+        // coordinates -- loads return in order, so waiting for a label read issued after them drains them all
         double znext[DP];
-        load_frame(fidx[0] < n ? fidx[0] : n - 1, znext);
+        int old_next = -1;
+        if constexpr (ACCUM) {
+            if (labels) old_next = labels[fidx[0] < n ? fidx[0] : n - 1];
+        }
+        load_frame(fidx[0] < n ? fidx[0] : n - 1, znext, vec_tag);
 #pragma unroll 1
         for (int u = 0; u < NF; ++u) {
             const int64_t f0 = fidx[0];
@@ -461,7 +478,13 @@ __global__ __launch_bounds__(1024, 4) void kmeans_filter_kernel(
             double z[DP];
 #pragma unroll
             for (int f = 0; f < DP; ++f) z[f] = znext[f];
-            if (NF > 1) load_frame(fidx[1] < n ? fidx[1] : n - 1, znext);   // (the last trip re-reads its own frame)
+            const int old = old_next;
+            if (NF > 1) {   // (the last trip re-reads its own frame)
+                if constexpr (ACCUM) {
+                    if (labels) old_next = labels[fidx[1] < n ? fidx[1] : n - 1];
+                }
+                load_frame(fidx[1] < n ? fidx[1] : n - 1, znext, vec_tag);
+            }
             const int cd = code[0];
             const float Ru = R[0];
 #pragma unroll
@@ -481,7 +504,6 @@ __global__ __launch_bounds__(1024, 4) void kmeans_filter_kernel(
                 if constexpr (ACCUM) {
                     // delta mode (labels != NULL): the sums follow the frames that CHANGED centre since the last pass
                     // (integer sums: the same bits as a full re-accumulation); else every frame is added
-                    const int old = labels ? labels[f0] : -1;
                     if (!labels || old != bi) {
                         // lane q adds features q, q + 4, q + 8
 #pragma unroll
@@ -516,7 +538,7 @@ __global__ __launch_bounds__(1024, 4) void kmeans_filter_kernel(
                 todo &= todo - 1;
                 const int64_t t = f0 - j16 + jf;
                 double zz[DP];
-                load_frame(t, zz);
+                load_frame(t, zz, vec_tag);
                 double sbest = -__builtin_inf();
                 int sbi = 0x7fffffff;
                 for (int c = lane; c < k; c += 64) {
@@ -554,6 +576,9 @@ __global__ __launch_bounds__(1024, 4) void kmeans_filter_kernel(
             }
             KSTAMP(6);
         }
+        };
+        if (vec_rows) refine_unit(std::true_type{});
+        else refine_unit(std::false_type{});
         unit = nxt;
     }
     KSTAMP(7);
