@@ -548,6 +548,18 @@ __device__ __forceinline__ double mov_dpp64(double x) {
     const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), CTRL, 0xf, 0xf, true);
     return __longlong_as_double(((long long)hi << 32) | (unsigned)lo);
 }
+// the bare v_max_f64 / v_min_f64 (operands never NaN where these are used): fmax() on a value that came through a DPP
+// move costs an extra canonicalising v_max_f64 per call
+__device__ __forceinline__ double hw_max_f64(double a, double b) {
+    double r;
+    asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ double hw_min_f64(double a, double b) {
+    double r;
+    asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
 typedef unsigned tri_v2u32 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ double sum8_dpp(double x) {   // sum over aligned groups of 8 lanes
     x += mov_dpp64<0xB1>(x);    // quad_perm [1,0,3,2]
@@ -612,31 +624,41 @@ __device__ __forceinline__ void mfma_mm(double* C, const double* A, const double
     __syncthreads();
 }
 
-// # eigenvalues of the (scaled) tridiagonal matrix below x: sign changes of p_{-1} = 1, p_0, ..., p_{n-1}, read off
-// the sign bits (an exact zero counts as positive: it only occurs when x is an eigenvalue of a leading block, and a
-// bracket spoilt by it fails the residual check).  Eight rows at a time: their {d, e^2} pairs come out of the LDS in
-// one burst; per row 5 vector instructions (sub, mul, fma, xor, alignbit).
+// # eigenvalues of the (scaled) tridiagonal matrix below x: sign changes of p_{-1} = 1, p_0, ..., p_{n-1}.  The sign
+// bits are shifted into a mask as the rows go by (one v_alignbit per row) and the changes counted at the end,
+// popc(S ^ (S >> 1)) per 32 rows: per row 4 vector instructions (sub, mul, fma, alignbit).  An exact zero counts as
+// positive: it only occurs when x is an eigenvalue of a leading block, and a bracket spoilt by it fails the residual
+// check.  Eight rows at a time: their {d, e^2} pairs come out of the LDS in one burst.
 __device__ __forceinline__ int sturm_count(const TriShared* ts, int nblocks, double x) {
     double pp = 0.0, p = 1.0;
-    unsigned bits = 0, cnt = 0;
+    unsigned bits = 0, w0 = 0;
     for (int b = 0; b < nblocks; ++b) {
+        // the rows are re-read from the LDS on every call: kept in registers across the rounds of the caller they
+        // would take 2 x 128 registers, and the compiler spills to scratch to try
+        asm volatile("" ::: "memory");
         double2 r[8];
 #pragma unroll
         for (int u = 0; u < 8; ++u) r[u] = ts->de[8 * b + u];
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
             const double pn = fma(r[u].x - x, p, -(r[u].y * pp));
-            bits = __builtin_amdgcn_alignbit(bits, (unsigned)(__double2hiint(pn) ^ __double2hiint(p)), 31);
+            bits = __builtin_amdgcn_alignbit(bits, (unsigned)__double2hiint(pn), 31);   // (bits << 1) | sign(pn)
             pp = p;
             p = pn;
         }
-        // keep the pair in range (the matrix is scaled to |T| <= 1, so eight rows cannot leave it)
-        const int ex = max(__builtin_amdgcn_frexp_exp(p), __builtin_amdgcn_frexp_exp(pp));
-        p = ldexp(p, -ex);
-        pp = ldexp(pp, -ex);
-        if ((b & 3) == 3) { cnt += __popc(bits); bits = 0; }
+        if (b & 1) {
+            // keep the pair in range: the matrix is scaled to |T| <= 1, so sixteen rows grow it by 2.5^16 at most and
+            // cannot shrink it below the normal range unless x sits within 1e-19 of sixteen diagonal entries in a row
+            const int ex = max(__builtin_amdgcn_frexp_exp(p), __builtin_amdgcn_frexp_exp(pp));
+            p = ldexp(p, -ex);
+            pp = ldexp(pp, -ex);
+        }
+        if (b == 3) { w0 = bits; bits = 0; }
     }
-    return (int)(cnt + __popc(bits));
+    if (nblocks <= 4) return __popc(bits ^ (bits >> 1));   // right-aligned: the zeros above stand for p_{-1} > 0
+    // rows 32.. sit right-aligned in `bits`; the row above the first of them is row 31 = bit 0 of w0
+    const int r1 = 8 * nblocks - 32;
+    return __popc(w0 ^ (w0 >> 1)) + __popc(bits ^ ((bits >> 1) | ((w0 & 1u) << (r1 - 1))));
 }
 
 // Tridiagonalisation A = Q T Q' with the matrices held in REGISTERS, every wave of the workgroup at work, two
@@ -980,9 +1002,9 @@ __device__ __forceinline__ bool tridiag_eigh(double* A, double* Q, double* X, in
             const double x = fma(hi - lo, frac, lo);
             const int c = sturm_count(ts, nblocks, x);
             double nlo = c <= i ? x : lo, nhi = c > i ? x : hi;
-            nlo = fmax(nlo, mov_dpp64<0xB1>(nlo)); nhi = fmin(nhi, mov_dpp64<0xB1>(nhi));
-            nlo = fmax(nlo, mov_dpp64<0x4E>(nlo)); nhi = fmin(nhi, mov_dpp64<0x4E>(nhi));
-            nlo = fmax(nlo, mov_dpp64<0x141>(nlo)); nhi = fmin(nhi, mov_dpp64<0x141>(nhi));
+            nlo = hw_max_f64(nlo, mov_dpp64<0xB1>(nlo)); nhi = hw_min_f64(nhi, mov_dpp64<0xB1>(nhi));
+            nlo = hw_max_f64(nlo, mov_dpp64<0x4E>(nlo)); nhi = hw_min_f64(nhi, mov_dpp64<0x4E>(nhi));
+            nlo = hw_max_f64(nlo, mov_dpp64<0x141>(nlo)); nhi = hw_min_f64(nhi, mov_dpp64<0x141>(nhi));
             lo = nlo;
             hi = nhi;
         }
