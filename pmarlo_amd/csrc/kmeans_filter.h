@@ -405,7 +405,11 @@ __global__ __launch_bounds__(1024, 4) void kmeans_filter_kernel(
         int bp[NF];
 #pragma unroll
         for (int u = 0; u < NF; ++u) { b1[u] = -__builtin_inff(); b2[u] = -__builtin_inff(); bp[u] = 0; }
+#ifdef MSM_KMF_DIAG_NOTILE   // timing experiments only (tools/build_variant.sh): wrong results
+        for (int jt = 0; jt < 2; jt += 2) {
+#else
         for (int jt = 0; jt < n_tiles; jt += 2) {
+#endif
             v8bf aa[NM], ab[NM];
 #pragma unroll
             for (int m = 0; m < NM; ++m) {
@@ -425,6 +429,11 @@ __global__ __launch_bounds__(1024, 4) void kmeans_filter_kernel(
                     accb[u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ab[1], b[u][1], accb[u], 0, 0, 0);
                 }
             }
+#ifdef MSM_KMF_DIAG_NOTOP2
+#pragma unroll
+            for (int u = 0; u < NF; ++u) asm volatile("" ::"v"(acca[u]), "v"(accb[u]));
+            if (jt == 0)
+#endif
 #pragma unroll
             for (int u = 0; u < NF; ++u) {
                 // m = max(b2, pair maximum): b2 <= b1, so the top-two update below is the same as with the bare
@@ -456,79 +465,61 @@ __global__ __launch_bounds__(1024, 4) void kmeans_filter_kernel(
             R[u] = xrow_max_f32(r);
         }
         KSTAMP(3);
-        // ---- refinement, frame group by frame group; the coordinates of the next group are in flight meanwhile.
-        // The loop is NOT unrolled (one copy of this long body keeps the scalar registers in hand): the per-group
-        // values rotate through slot 0 instead.
-        // (one copy of the loop per row-load flavour: with the flavour chosen inside, the two load sequences met in
-        // front of the scoring chain and the wait counts there fell back to draining the loads just issued for the
-        // NEXT group -- the prefetch hid nothing)
+        // ---- refinement, one frame per lane: lane (q, j16) takes frame j16 of group u = q -- its own eight
+        // candidates (rows 4 gs .. 4 gs + 3 of both tiles of the winning pair) scored one after the other with the
+        // pinned fp64 chain, no cross-lane arg-max, one pass over the unit instead of one per group (the four lanes
+        // of a frame used to score two rows each and settle the winner by butterflies, 16 frames at a time).
+        // (one copy of the code per row-load flavour: chosen inside, the two load sequences met in front of the
+        // scoring chain and the wait counts there fell back to draining everything in flight)
+        static_assert(NF <= 4, "one frame group per lane quarter");
         auto refine_unit = [&](auto vec_tag) {
-        // delta mode: the previous label of a frame is fetched one group ahead too, and BEFORE that group's
-        // coordinates -- loads return in order, so waiting for a label read issued after them drains them all
-        double znext[DP];
-        int old_next = -1;
-        if constexpr (ACCUM) {
-            if (labels) old_next = labels[fidx[0] < n ? fidx[0] : n - 1];
-        }
-        load_frame(fidx[0] < n ? fidx[0] : n - 1, znext, vec_tag);
-#pragma unroll 1
-        for (int u = 0; u < NF; ++u) {
-            const int64_t f0 = fidx[0];
-            const bool fok = f0 < n;
-            double z[DP];
+            int cd = code[0];
+            float Ru = R[0];
+            int64_t f0 = fidx[0];
 #pragma unroll
-            for (int f = 0; f < DP; ++f) z[f] = znext[f];
-            const int old = old_next;
-            if (NF > 1) {   // (the last trip re-reads its own frame)
-                if constexpr (ACCUM) {
-                    if (labels) old_next = labels[fidx[1] < n ? fidx[1] : n - 1];
-                }
-                load_frame(fidx[1] < n ? fidx[1] : n - 1, znext, vec_tag);
+            for (int u = 1; u < NF; ++u)
+                if (q == u) { cd = code[u]; Ru = R[u]; f0 = fidx[u]; }
+            const bool fok = q < NF && f0 < n;
+            const int64_t fr = fok ? f0 : n - 1;
+            // delta mode: the previous label goes out BEFORE the coordinates -- loads return in order
+            int old = -1;
+            if constexpr (ACCUM) {
+                if (labels) old = labels[fr];
             }
-            const int cd = code[0];
-            const float Ru = R[0];
-#pragma unroll
-            for (int v = 0; v + 1 < NF; ++v) { fidx[v] = fidx[v + 1]; code[v] = code[v + 1]; R[v] = R[v + 1]; }
+            double z[DP];
+            load_frame(fr, z, vec_tag);
             const int gs = cd >> 16, pstar = cd & 0xffff;
-            // this lane re-scores row 4 gs + q of both tiles of the pair
-            const int ia = min(pstar * 16 + 4 * gs + q, n_tiles * 16 - 17), ib = ia + 16;
-            double best = score(cs64 + (size_t)ia * D1, z);
-            int bi = ia;
-            const double sb = score(cs64 + (size_t)ib * D1, z);
-            if (sb > best) { best = sb; bi = ib; }          // ia < ib: ties keep ia
-            xrow_argmax_f64(best, bi);
+            const int base = min(pstar * 16 + 4 * gs, n_tiles * 16 - 20);   // (the clamp only meets the "no candidate" code)
+            double best = score(cs64 + (size_t)base * D1, z);
+            int bi = base;
+#pragma unroll
+            for (int c = 1; c < 8; ++c) {   // ascending row index: ties keep the lower one
+                const int row = base + (c & 3) + 16 * (c >> 2);
+                const double s = score(cs64 + (size_t)row * D1, z);
+                if (s > best) { best = s; bi = row; }
+            }
             const bool certified = !all_scan && cd != 0x7fffffff && bi < k && best > (double)Ru;   // false for NaN
-            unsigned long long todo = __ballot(fok && !certified) & 0xFFFFull;   // one bit per frame (lanes q = 0)
+            unsigned long long todo = __ballot(fok && !certified);   // one bit per frame
             KSTAMP(4);
             if (fok && certified) {
                 if constexpr (ACCUM) {
                     // delta mode (labels != NULL): the sums follow the frames that CHANGED centre since the last pass
                     // (integer sums: the same bits as a full re-accumulation); else every frame is added
                     if (!labels || old != bi) {
-                        // lane q adds features q, q + 4, q + 8
 #pragma unroll
-                        for (int i = 0; i < (DP + 3) / 4; ++i) {
-                            double v = z[4 * i];
-                            if (4 * i + 1 < DP) v = q == 1 ? z[4 * i + 1] : v;
-                            if (4 * i + 2 < DP) v = q == 2 ? z[4 * i + 2] : v;
-                            if (4 * i + 3 < DP) v = q == 3 ? z[4 * i + 3] : v;
-                            const int f = 4 * i + q;
+                        for (int f = 0; f < DP; ++f) {
                             if (f < d) {
-                                const unsigned long long fx = (unsigned long long)to_fixed(v, scale);
+                                const unsigned long long fx = (unsigned long long)to_fixed(z[f], scale);
                                 atomicAdd(&lsum[(size_t)bi * d + f], fx);
                                 if (old >= 0) atomicAdd(&lsum[(size_t)old * d + f], 0ull - fx);
                             }
                         }
-                        if (q == 0) {
-                            atomicAdd(&lcnt[bi], 1ull);
-                            if (old >= 0) atomicAdd(&lcnt[old], ~0ull);
-                        }
+                        atomicAdd(&lcnt[bi], 1ull);
+                        if (old >= 0) atomicAdd(&lcnt[old], ~0ull);
+                        if (labels) labels[f0] = bi;
                     }
                 } else {
-                    if (q == 0) write_label(f0, bi, best, z);
-                }
-                if constexpr (ACCUM) {
-                    if (labels && q == 0) labels[f0] = bi;
+                    write_label(f0, bi, best, z);
                 }
             }
             KSTAMP(5);
@@ -536,7 +527,8 @@ __global__ __launch_bounds__(1024, 4) void kmeans_filter_kernel(
             while (todo) {
                 const int jf = __builtin_ctzll(todo);
                 todo &= todo - 1;
-                const int64_t t = f0 - j16 + jf;
+                const int64_t t = ((int64_t)__builtin_amdgcn_readlane((int)(f0 >> 32), jf) << 32) |
+                                  (unsigned)__builtin_amdgcn_readlane((int)f0, jf);
                 double zz[DP];
                 load_frame(t, zz, vec_tag);
                 double sbest = -__builtin_inf();
@@ -553,19 +545,19 @@ __global__ __launch_bounds__(1024, 4) void kmeans_filter_kernel(
                 }
                 if (sbi >= k) { sbi = 0; sbest = -__builtin_inf(); }   // every score NaN: label 0, as the fp64 kernel
                 if constexpr (ACCUM) {
-                    const int old = labels ? labels[t] : -1;
-                    if (!labels || old != sbi) {
+                    const int old_s = labels ? labels[t] : -1;
+                    if (!labels || old_s != sbi) {
                         double v = zz[0];                                   // lane f adds feature f
 #pragma unroll
                         for (int f = 1; f < DP; ++f) v = lane == f ? zz[f] : v;
                         if (lane < d) {
                             const unsigned long long fx = (unsigned long long)to_fixed(v, scale);
                             atomicAdd(&lsum[(size_t)sbi * d + lane], fx);
-                            if (old >= 0) atomicAdd(&lsum[(size_t)old * d + lane], 0ull - fx);
+                            if (old_s >= 0) atomicAdd(&lsum[(size_t)old_s * d + lane], 0ull - fx);
                         }
                         if (lane == 0) {
                             atomicAdd(&lcnt[sbi], 1ull);
-                            if (old >= 0) atomicAdd(&lcnt[old], ~0ull);
+                            if (old_s >= 0) atomicAdd(&lcnt[old_s], ~0ull);
                             if (labels) labels[t] = sbi;
                         }
                     }
@@ -575,10 +567,13 @@ __global__ __launch_bounds__(1024, 4) void kmeans_filter_kernel(
                 ++my_scans;
             }
             KSTAMP(6);
-        }
         };
+#ifndef MSM_KMF_DIAG_NOREFINE
         if (vec_rows) refine_unit(std::true_type{});
         else refine_unit(std::false_type{});
+#else
+        if (lane == 0 && code[0] == 12345) labels[0] = (int)R[0] + code[1] + code[2] + code[3];
+#endif
         unit = nxt;
     }
     KSTAMP(7);

@@ -43,6 +43,17 @@ def main():
     elif stage == "tica":
         eng.lagged_moments(xd, lag, mean, out=mom, assume_finite=True)
         med, mn = timeit(eng, lambda: eng.tica_solve(mom, F, scale=std))
+    elif stage == "kmeans":   # assign / accumulate passes at the bench shard (wrong results are fine for diagnostic variants)
+        from pmarlo_amd.dist import ShardConfig, ShardedMSM
+        d, k = 10, 500
+        rng = np.random.default_rng(0)
+        Y = eng.to_device(rng.normal(size=(n, d)))
+        cen = eng.to_device(rng.normal(size=(k, d)))
+        lab = eng.empty((n,), np.int32)
+        img = eng.kmeans_pack(Y)
+        med, mn = timeit(eng, lambda: eng.kmeans_assign(Y, cen, labels=lab, image=img))
+        print(f"{sys.argv[1]:48s} kmeans assign: median {med * 1e3:8.1f} us  min {mn * 1e3:8.1f} us")
+        return
     else:
         raise SystemExit("stage?")
     print(f"{sys.argv[1]:48s} {stage}: median {med * 1e3:8.1f} us  min {mn * 1e3:8.1f} us  checksum {float(np.abs(mom.to_host()).sum()):.17g}")
