@@ -450,19 +450,24 @@ __global__ __launch_bounds__(1024, 4) void kmeans_filter_kernel(
         }
         KSTAMP(2);
         // ---- the winning lane, its pair and the bound R on everything outside its 8 candidates, per frame
-        int code[NF];
-        float R[NF];
+        // lane (q, j16) keeps the values of group u = q, the frame it refines below (selected here, one group at a
+        // time: picked out of per-group arrays afterwards, the arrays were indexed by q and went to scratch memory --
+        // 64 bytes per frame of extra HBM writes)
+        int cd = 0x7fffffff;
+        float Ru = __builtin_inff();
 #pragma unroll
         for (int u = 0; u < NF; ++u) {
             const float M1 = xrow_max_f32(b1[u]);
             // lowest holder lane q and its pair, in one minimum: (q << 16) | pair
-            code[u] = xrow_min_i32(b1[u] == M1 ? ((q << 16) | bp[u]) : 0x7fffffff);
-            const int gs = code[u] >> 16;
+            const int code_u = xrow_min_i32(b1[u] == M1 ? ((q << 16) | bp[u]) : 0x7fffffff);
+            const int gs = code_u >> 16;
             float r = q == gs ? b2[u] : b1[u];
             // range guard of the frame: the last slot of its image row (lane q = 3 of the last instruction) is +inf;
             // an infinite R refuses the certificate
             if (q == 3 && __builtin_bit_cast(unsigned short, b[u][NM - 1][7]) == 0x7F80) r = __builtin_inff();
-            R[u] = xrow_max_f32(r);
+            const float R_u = xrow_max_f32(r);
+            cd = q == u ? code_u : cd;
+            Ru = q == u ? R_u : Ru;
         }
         KSTAMP(3);
         // ---- refinement, one frame per lane: lane (q, j16) takes frame j16 of group u = q -- its own eight
@@ -473,12 +478,7 @@ __global__ __launch_bounds__(1024, 4) void kmeans_filter_kernel(
         // scoring chain and the wait counts there fell back to draining everything in flight)
         static_assert(NF <= 4, "one frame group per lane quarter");
         auto refine_unit = [&](auto vec_tag) {
-            int cd = code[0];
-            float Ru = R[0];
-            int64_t f0 = fidx[0];
-#pragma unroll
-            for (int u = 1; u < NF; ++u)
-                if (q == u) { cd = code[u]; Ru = R[u]; f0 = fidx[u]; }
+            const int64_t f0 = unit * frames_per_wave + lane;   // = fidx[q]
             const bool fok = q < NF && f0 < n;
             const int64_t fr = fok ? f0 : n - 1;
             // delta mode: the previous label goes out BEFORE the coordinates -- loads return in order
@@ -572,7 +572,7 @@ __global__ __launch_bounds__(1024, 4) void kmeans_filter_kernel(
         if (vec_rows) refine_unit(std::true_type{});
         else refine_unit(std::false_type{});
 #else
-        if (lane == 0 && code[0] == 12345) labels[0] = (int)R[0] + code[1] + code[2] + code[3];
+        if (lane == 0 && cd == 12345) labels[0] = (int)Ru;
 #endif
         unit = nxt;
     }
