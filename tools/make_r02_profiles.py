@@ -21,7 +21,8 @@ def main():
                     "7 steps (2 warm-up + 5 timed) + the parity block's calls; tools/run/prof_r02.sh.  The state at the "
                     "middle of the round (before the register-resident TICA solve, the resident-grid projection, the "
                     "LDS-staged frame images, the interior loop of the covariance pass and the in-kernel centre tables) "
-                    "is in git history (commit 164fd9e)."], check=True, capture_output=True)
+                    "is in git history (commit 164fd9e); the state before the symmetric covariance accumulation, the "
+                    "sixteen-wave tridiagonalisation and the one-frame-per-lane k-means refinement in commit 59e0739."], check=True, capture_output=True)
     dirs = [str(ROOT / f"gpurun_out/pmc_r02_{i}") for i in range(4)]
     table = subprocess.run([sys.executable, str(ROOT / "tools/pmc_summary.py"), *dirs, "--json", "/tmp/pmc.json"],
                            check=True, capture_output=True, text=True).stdout
@@ -46,7 +47,7 @@ def main():
             "overlap on this chip.", ""]
     (P / "r02_pmc.md").write_text("\n".join(head) + table)
     alg = {"kmeans_filter_kernel<double, 2, 4, true, false>": 208, "kmeans_filter_kernel<double, 2, 4, false, false>": 212,
-           "cov_fused_kernel<float, 4, true, true, true>": 256, "project_mfma_kernel<float, true>": 336,
+           "cov_fused_kernel<float, 4, true, true, true, true>": 256, "cov_fused_kernel<float, 4, true, true, true>": 256, "project_mfma_kernel<float, true>": 336,
            "kmeans_pack_kernel<double, 10>": 208, "count_lds_kernel<false>": 4, "moments_partial_kernel<float>": 256}
     rows = [(k, v["dispatches"], v["FETCH_SIZE"], v["WRITE_SIZE"], (2 * v["FETCH_SIZE"] + v["WRITE_SIZE"]) * 1024 / 1e6)
             for k, v in d.items() if v.get("FETCH_SIZE") is not None and v.get("WRITE_SIZE") is not None]
