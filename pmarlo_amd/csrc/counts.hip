@@ -156,6 +156,9 @@ CountPlan plan_counts(const msm_ctx* ctx, int k, int64_t total_pairs, size_t bin
     size_t budget = (row_bytes * k <= (size_t)kLdsBudgetSmall) ? kLdsBudgetSmall : kLdsBudgetLarge;
     int rows = (int)(budget / row_bytes);
     if (rows > k) rows = k;
+#ifdef MSM_COUNTS_FORCE_GLOBAL   // timing experiment (tools/build_variant.sh)
+    rows = 0;
+#endif
     if (rows < 1 || msm_ceil_div(k, rows) > kMaxRowBlocks) {
         pl.global_path = true;
         pl.chunks = (int)std::min<int64_t>(std::max<int64_t>(1, msm_ceil_div(total_pairs, kThreads * 8)),

@@ -578,6 +578,7 @@ __global__ __launch_bounds__(1024, 4) void kmeans_filter_kernel(
     }
     KSTAMP(7);
     if (n_scanned && lane == 0 && my_scans) atomicAdd(n_scanned, my_scans);
+#ifndef MSM_KMF_DIAG_NOFLUSH
     if constexpr (ACCUM) {
         __syncthreads();
         for (int i = tid; i < k * d; i += kMT)
@@ -585,6 +586,7 @@ __global__ __launch_bounds__(1024, 4) void kmeans_filter_kernel(
         for (int i = tid; i < k; i += kMT)
             if (lcnt[i]) atomicAdd(&counts[i], lcnt[i]);
     }
+#endif
     KSTAMP_FLUSH
 }
 

@@ -53,6 +53,20 @@ def main():
         img = eng.kmeans_pack(Y)
         med, mn = timeit(eng, lambda: eng.kmeans_assign(Y, cen, labels=lab, image=img))
         print(f"{sys.argv[1]:48s} kmeans assign: median {med * 1e3:8.1f} us  min {mn * 1e3:8.1f} us")
+        # accumulate passes: full sums, then delta sums against labels that barely move
+        cfg = ShardConfig(n_frames=n, n_features=F, tica_dim=d, k=k, lag=lag, kmeans_iters=10, seed=0, n_total=n)
+        msm = ShardedMSM(eng, cfg, xd)
+        msm.step()
+        st = msm.buf["fit_state"]
+        sums, counts = eng.zeros((k * d,), np.int64), eng.zeros((k,), np.int64)
+        img2 = eng.kmeans_pack(msm.Y)
+        med, mn = timeit(eng, lambda: eng.kmeans_accumulate(msm.Y, msm.buf["centers"], st, sums, counts, image=img2))
+        print(f"{sys.argv[1]:48s} kmeans accumulate (full): median {med * 1e3:8.1f} us  min {mn * 1e3:8.1f} us")
+        prev = eng.empty((n,), np.int32)
+        prev.fill_bytes_(0xFF)
+        eng.kmeans_accumulate(msm.Y, msm.buf["centers"], st, sums, counts, image=img2, prev_labels=prev)
+        med, mn = timeit(eng, lambda: eng.kmeans_accumulate(msm.Y, msm.buf["centers"], st, sums, counts, image=img2, prev_labels=prev))
+        print(f"{sys.argv[1]:48s} kmeans accumulate (delta, nothing moves): median {med * 1e3:8.1f} us  min {mn * 1e3:8.1f} us")
         return
     else:
         raise SystemExit("stage?")
