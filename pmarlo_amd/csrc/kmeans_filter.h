@@ -176,20 +176,53 @@ struct FilterShape {
     static constexpr int kTileBytes = NM * 1024 + 16 * D1 * 8;    // image + table rows of one 16-centre tile
 };
 
-// One wave stages one 16-centre tile (simg: NM * 64 * 8 shorts of LDS of its own).  `centers`, `cs_g` and `flag` may
-// be global or LDS; the table rows go to cs_g + j * D1.
+// One wave stages one 16-centre tile (simg: NM * 64 * 8 shorts of LDS of its own) in two steps, so that a wave with
+// several tiles has the global loads of all of them in flight before it builds the first (the build is ~300
+// instructions; one load round trip under load is as long):
+//   filter_stage_fetch: the tile's 16 x d coordinates, one coalesced load per 64 elements (element e = row e / d,
+//                       feature e % d), at most kStageRegs per lane;
+//   filter_stage_build: bf16 triples into the A operands, coordinates into the table rows; the 16 row lanes then read
+//                       their row back from the LDS for h_j, the range guard and the kappa slots (same chain, same bits).
+// `cs_g` and `flag` may be global or LDS (in-order within the wave either way); the table rows go to cs_g + j * D1.
+constexpr int kStageRegs = (16 * kFilterMaxD + 63) / 64;
+// i / d for 0 <= i < 256, 1 <= d <= 10 without the integer-division sequence: (i + 0.5) / d is at least 0.05 away from
+// every integer, far outside fp32 rounding
+__device__ __forceinline__ int stage_row(int i, int d) { return (int)(((float)i + 0.5f) * (1.0f / (float)d)); }
+__device__ __forceinline__ void filter_stage_fetch(int tile, int lane, const double* __restrict__ centers, int k, int d,
+                                                   double (&c)[kStageRegs]) {
+#pragma unroll
+    for (int u = 0; u < kStageRegs; ++u) {
+        const int i = lane + 64 * u;
+        const int r = stage_row(i, d), j = tile * 16 + r;
+        c[u] = (i < 16 * d && j < k) ? centers[(size_t)tile * 16 * d + i] : 0.0;
+    }
+}
 template <int NM>
-__device__ __forceinline__ void filter_stage_tile(int tile, int lane, unsigned short* simg, const double* centers, int k,
-                                                  int d, uint4* __restrict__ img_g, double* __restrict__ cs_g,
-                                                  int* __restrict__ flag) {
+__device__ __forceinline__ void filter_stage_build(int tile, int lane, unsigned short* simg, const double (&c)[kStageRegs],
+                                                   int k, int d, uint4* __restrict__ img_g, double* __restrict__ cs_g,
+                                                   int* __restrict__ flag) {
     using S = FilterShape<NM>;
     constexpr double kappa = filter_kappa(NM);
     for (int i = lane; i < NM * 64 * 4; i += 64) reinterpret_cast<unsigned*>(simg)[i] = 0u;
+    for (int i = lane; i < 16 * S::D1; i += 64) cs_g[(size_t)tile * 16 * S::D1 + i] = 0.0;   // pads beyond d, h and pad slots
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");   // one wave, LDS in order: only the compiler must not reorder
     auto slot_addr = [&](int i, int sl) {      // bf16 element of tile row i, slot sl
         const int m = sl >> 5, qq = (sl & 31) >> 3, e = sl & 7;
         return ((m * 64) + qq * 16 + i) * 8 + e;
     };
+#pragma unroll
+    for (int u = 0; u < kStageRegs; ++u) {
+        const int i = lane + 64 * u;
+        const int r = stage_row(i, d), f = i - r * d, j = tile * 16 + r;
+        if (i < 16 * d && j < k) {
+            unsigned cp[3];
+            bf16_split3(c[u], cp);
+#pragma unroll
+            for (int t = 0; t < 6; ++t) simg[slot_addr(r, t * d + f)] = (unsigned short)cp[filter_part_c(t)];
+            cs_g[(size_t)j * S::D1 + f] = c[u];
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     int bad_row = 0;
     if (lane < 16) {
         const int j = tile * 16 + lane;
@@ -198,12 +231,12 @@ __device__ __forceinline__ void filter_stage_tile(int tile, int lane, unsigned s
         if (j < k) {
             double a = 0.0;
             bool ok = true;
+#pragma unroll
             for (int f = 0; f < S::DP; ++f) {
-                const double c = f < d ? centers[(size_t)j * d + f] : 0.0;
-                row[f] = c;
-                a = fma(c, c, a);
-                const double ac = fabs(c);
-                ok = ok && (c == 0.0 || (ac >= kFilterLo && ac <= kFilterHi));
+                const double cf = row[f];   // zero beyond d
+                a = fma(cf, cf, a);
+                const double ac = fabs(cf);
+                ok = ok && (cf == 0.0 || (ac >= kFilterLo && ac <= kFilterHi));
             }
             h = 0.5 * a;
             if (!ok) bad_row = 1;
@@ -215,26 +248,23 @@ __device__ __forceinline__ void filter_stage_tile(int tile, int lane, unsigned s
             simg[slot_addr(lane, 32 * NM - 1)] =
                 (unsigned short)bf16_up((float)(kappa * sqrt(a) * (1.0 + 9.5367431640625e-07)));
         } else {
-            for (int f = 0; f < S::DP; ++f) row[f] = 0.0;
             simg[slot_addr(lane, 6 * d)] = 0xFF7F;   // -3.4e38 x 1.0: a padding centre never holds a maximum
         }
         row[S::DP] = h;
-        row[S::DP + 1] = 0.0;
-    }
-    for (int i = lane; i < 16 * d; i += 64) {
-        const int r = i / d, f = i - r * d, j = tile * 16 + r;
-        if (j < k) {
-            unsigned cp[3];
-            bf16_split3(centers[(size_t)j * d + f], cp);
-#pragma unroll
-            for (int t = 0; t < 6; ++t) simg[slot_addr(r, t * d + f)] = (unsigned short)cp[filter_part_c(t)];
-        }
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     if (img_g)   // NULL: `simg` is the image's final place (the main kernel stages into its own LDS)
         for (int i = lane; i < NM * 64; i += 64) img_g[(size_t)tile * NM * 64 + i] = reinterpret_cast<const uint4*>(simg)[i];
     const bool any_bad = __any(bad_row != 0);      // every staging rewrites its flag
     if (lane == 0) flag[tile] = any_bad ? 1 : 0;
+}
+template <int NM>
+__device__ __forceinline__ void filter_stage_tile(int tile, int lane, unsigned short* simg, const double* centers, int k,
+                                                  int d, uint4* __restrict__ img_g, double* __restrict__ cs_g,
+                                                  int* __restrict__ flag) {
+    double c[kStageRegs];
+    filter_stage_fetch(tile, lane, centers, k, d, c);
+    filter_stage_build<NM>(tile, lane, simg, c, k, d, img_g, cs_g, flag);
 }
 
 // cross-row butterflies over the 4 lanes (j, j + 16, j + 32, j + 48) that share a frame: v_permlane16_swap /
@@ -314,9 +344,18 @@ __global__ __launch_bounds__(1024, 4) void kmeans_filter_kernel(
     // LDS (a separate staging launch + 113 KB of copies per workgroup did the same for 4.7 us more per pass)
     __shared__ int tile_flag[64];
     {
-        for (int t = wave; t < n_tiles; t += kMT / 64)   // padding tiles too: their rows carry the -inf sentinel
-            filter_stage_tile<NM>(t, lane, reinterpret_cast<unsigned short*>(img + (size_t)t * NM * 64), centers, k, d,
-                                  nullptr, cs64, tile_flag);
+        // padding tiles too (their rows carry the -inf sentinel); two tiles per trip, both fetched before either is built
+        for (int t = wave; t < n_tiles; t += 2 * (kMT / 64)) {
+            const int t2 = t + kMT / 64;
+            double c0[kStageRegs], c1[kStageRegs];
+            filter_stage_fetch(t, lane, centers, k, d, c0);
+            if (t2 < n_tiles) filter_stage_fetch(t2, lane, centers, k, d, c1);
+            filter_stage_build<NM>(t, lane, reinterpret_cast<unsigned short*>(img + (size_t)t * NM * 64), c0, k, d, nullptr, cs64,
+                                   tile_flag);
+            if (t2 < n_tiles)
+                filter_stage_build<NM>(t2, lane, reinterpret_cast<unsigned short*>(img + (size_t)t2 * NM * 64), c1, k, d, nullptr,
+                                       cs64, tile_flag);
+        }
     }
     __syncthreads();
     int bad_tiles = 0;
