@@ -106,7 +106,8 @@ def test_lagged_moments_symmetric_exact_integers(engine):
     for bit on every kernel shape (F = 48 and 64: symmetric tiles; 20: plain pass + in-place symmetrisation; 80: blocked)."""
     rng = np.random.default_rng(5)
     for n, F, lag, dtype in [(1031, 64, 3, np.float32), (517, 48, 2, np.float64), (300, 20, 1, np.float32),
-                             (400, 80, 4, np.float64)]:
+                             (400, 80, 4, np.float64), (333, 50, 3, np.float32), (290, 63, 1, np.float64),
+                             (700, 33, 5, np.float32)]:   # 50, 63: four feature tiles without the vector loads; 33: three
         X = rng.integers(-3, 4, size=(n, F)).astype(dtype)
         X[:, 1] = np.arange(n) % 5
         segs = [(0, n // 3), (n // 3, n)]

@@ -18,7 +18,7 @@ rng = np.random.default_rng(int(sys.argv[1]) if len(sys.argv) > 1 else 0)
 n_cases = int(sys.argv[2]) if len(sys.argv) > 2 else 60
 bad = 0
 for case in range(n_cases):
-    F = int(rng.choice([1, 2, 3, 5, 8, 13, 16, 17, 31, 32, 33, 47, 64, 65, 100]))
+    F = int(rng.choice([1, 2, 3, 5, 8, 13, 16, 17, 31, 32, 33, 47, 50, 63, 64, 65, 100]))
     n = int(rng.integers(max(40, 3 * F), 5000))
     lag = int(rng.integers(1, 12))
     d = int(rng.integers(1, min(F, 12) + 1))
