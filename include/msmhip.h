@@ -304,6 +304,12 @@ msm_status msm_project(msm_ctx* ctx, const void* d_x, msm_dtype dtype, int64_t n
                        const double* d_mu, const double* d_inv_sigma, const double* d_mean2,
                        const double* d_w, int d, int64_t ldw, double* d_y, int64_t ldy, double* d_absmax);
 
+/* The same projection for X known to hold no NaN (msm_column_moments' d_count tells): the NaN test per element is
+ * left out, same results on finite data.  With NaNs present the plain entry must be used. */
+msm_status msm_project_finite(msm_ctx* ctx, const void* d_x, msm_dtype dtype, int64_t n, int F, int64_t ld,
+                              const double* d_mu, const double* d_inv_sigma, const double* d_mean2,
+                              const double* d_w, int d, int64_t ldw, double* d_y, int64_t ldy, double* d_absmax);
+
 /* Symmetric eigendecomposition by parallel cyclic Jacobi (n <= 256), ascending
  * eigenvalues d_w [n], eigenvectors in the columns of d_v [n, n] (may be NULL).
  * Replaces np.linalg.eigh on the path (e.g. _estimate_top_eigenvalues,

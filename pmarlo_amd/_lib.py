@@ -75,6 +75,7 @@ _PROTOTYPES: dict[str, tuple] = {
     "msm_onesided_tica_eigenvalues": (_i32, [_vp, _vp, _i32, _f64, _vp]),
     "msm_moments_from_lagged": (_i32, [_vp, _vp, _i32, _i64, _i32, _i64, _vp, _vp, _i32, _i32, _vp, _vp, _vp]),
     "msm_project": (_i32, [_vp, _vp, _i32, _i64, _i32, _i64, _vp, _vp, _vp, _vp, _i32, _i64, _vp, _i64, _vp]),
+    "msm_project_finite": (_i32, [_vp, _vp, _i32, _i64, _i32, _i64, _vp, _vp, _vp, _vp, _i32, _i64, _vp, _i64, _vp]),
     "msm_eigh": (_i32, [_vp, _vp, _i32, _vp, _vp, _vp]),
     "msm_kmeans_assign": (_i32, [_vp, _vp, _i32, _i64, _i32, _i64, _vp, _i32, _vp, _vp, _vp, _vp]),
     "msm_kmeans_fit": (_i32, [_vp, _vp, _i32, _i64, _i32, _i64, _vp, _vp, _i32, C.c_uint64, _i32, _i32, _f64, _vp, _vp]),

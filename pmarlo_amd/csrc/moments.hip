@@ -248,19 +248,24 @@ constexpr int kPChunk = 64;  // features per pipelined chunk (4 x 16-byte loads 
 // is one ds_read_b64, which keeps the kernel at <= 128 VGPRs (4 waves per SIMD) for any F.
 // VEC path: the raw 16-byte loads of the NEXT (frame group, chunk) are issued before the MFMAs
 // of the current one, so HBM latency overlaps the matrix work inside a wave as well.
-template <typename T, bool VEC>
+// FINITE (vector path): the caller vouches for X without NaNs (msm_project_finite; msm_column_moments' count tells) and the
+// NaN test -- three of the five vector instructions per element, all of them matrix-pipe time next to fp64 matrix
+// instructions -- is left out.
+template <typename T, bool VEC, bool FINITE = false>
 __global__ __launch_bounds__(kThreads) void project_mfma_kernel(
     const T* __restrict__ x, int64_t n, int F, int64_t ld, const double* __restrict__ mu,
     const double* __restrict__ inv_sigma, const double* __restrict__ m2, const double* __restrict__ W, int d,
     int64_t ldw, double* __restrict__ y, int64_t ldy, unsigned long long* __restrict__ absmax_bits) {
     extern __shared__ __attribute__((aligned(16))) unsigned char proj_smem[];
     double amax = 0.0;
-    double* wl = reinterpret_cast<double*>(proj_smem);  // [F16][16]
+    // W' as [F16 / 4][16 columns][4 features]: the four A operands a lane needs per 16-byte load of X are two 16-byte
+    // LDS reads (the scalar path below indexes the same layout)
+    double* wl = reinterpret_cast<double*>(proj_smem);
     const int F16 = (F + 15) & ~15;
     double* mul = wl + (size_t)F16 * 16;  // [F16]
     for (int idx = threadIdx.x; idx < F16 * 16; idx += kThreads) {
         const int f = idx >> 4, c = idx & 15;
-        wl[idx] = (f < F && c < d) ? inv_sigma[f] * W[(size_t)f * ldw + c] : 0.0;
+        wl[(f >> 2) * 64 + c * 4 + (f & 3)] = (f < F && c < d) ? inv_sigma[f] * W[(size_t)f * ldw + c] : 0.0;
     }
     for (int f = threadIdx.x; f < F16; f += kThreads) mul[f] = f < F ? mu[f] : 0.0;
     __syncthreads();
@@ -335,12 +340,19 @@ __global__ __launch_bounds__(kThreads) void project_mfma_kernel(
                 const int fq = ch * kPChunk + 16 * q + 4 * g;
                 const bool live = fq < F16;
                 const int fb = live ? fq : 0;
+                const double2* mp = reinterpret_cast<const double2*>(mul + fb);
+                const double2* wp = reinterpret_cast<const double2*>(wl + (fb >> 2) * 64 + j * 4);
+                const double2 m01 = mp[0], m23 = mp[1], w01 = wp[0], w23 = wp[1];
+                const double mv[4] = {m01.x, m01.y, m23.x, m23.y};
+                const double wv[4] = {w01.x, w01.y, w23.x, w23.y};
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     const double xv = (double)cur[q][i];
-                    double z = xv - mul[fb + i];
-                    if (!(xv == xv)) z = 0.0;
-                    const double w = live ? wl[(fb + i) * 16 + j] : 0.0;
+                    double z = xv - mv[i];
+                    if constexpr (!FINITE) {
+                        if (!(xv == xv)) z = 0.0;
+                    }
+                    const double w = live ? wv[i] : 0.0;
                     acc = __builtin_amdgcn_mfma_f64_16x16x4f64(w, z, acc, 0, 0, 0);
                 }
             }
@@ -371,7 +383,7 @@ __global__ __launch_bounds__(kThreads) void project_mfma_kernel(
                     const int f = f0 + 4 * g + i;
                     double z = zv[i] - mul[f];
                     if (!(zv[i] == zv[i]) || !tok || f >= F) z = 0.0;
-                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(wl[f * 16 + j], z, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(wl[(f >> 2) * 64 + j * 4 + (f & 3)], z, acc, 0, 0, 0);
                 }
             }
             store(grp, acc);
@@ -459,9 +471,9 @@ msm_status msm_column_moments(msm_ctx* ctx, const void* d_x, msm_dtype dtype, in
     return msm_moments_finalize(ctx, sums, shift, F, ddof, d_mean, d_std, d_count);
 }
 
-msm_status msm_project(msm_ctx* ctx, const void* d_x, msm_dtype dtype, int64_t n, int F, int64_t ld,
-                       const double* d_mu, const double* d_inv_sigma, const double* d_mean2, const double* d_w, int d,
-                       int64_t ldw, double* d_y, int64_t ldy, double* d_absmax) {
+static msm_status project_impl(msm_ctx* ctx, const void* d_x, msm_dtype dtype, int64_t n, int F, int64_t ld,
+                               const double* d_mu, const double* d_inv_sigma, const double* d_mean2, const double* d_w, int d,
+                               int64_t ldw, double* d_y, int64_t ldy, double* d_absmax, bool finite) {
     if (!ctx) return MSM_ERR_INVALID;
     MSM_REQUIRE(ctx, n >= 0 && F >= 1 && d >= 1 && d <= 64, "msm_project: need n >= 0, F >= 1, 1 <= d <= 64");
     unsigned long long* bits = reinterpret_cast<unsigned long long*>(d_absmax);
@@ -478,16 +490,16 @@ msm_status msm_project(msm_ctx* ctx, const void* d_x, msm_dtype dtype, int64_t n
         const bool vec = (F % 16 == 0) && (ld % 4 == 0) && (((uintptr_t)d_x) % (4 * esz) == 0);
         // one wave of workgroups: exactly as many as are resident at once (a grid of 8 per CU ran a second, thin round
         // behind the 6 per CU the registers allow)
-#define MSM_PROJ(T, V)                                                                                         \
+#define MSM_PROJ(T, V, FIN)                                                                                    \
         do {                                                                                                   \
             int per_cu = 0;                                                                                    \
-            MSM_HIP(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, project_mfma_kernel<T, V>, kThreads, plds)); \
+            MSM_HIP(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, project_mfma_kernel<T, V, FIN>, kThreads, plds)); \
             const int grid = (int)std::min<int64_t>((n_groups + 3) / 4, (int64_t)ctx->n_cu * std::max(per_cu, 1)); \
-            hipLaunchKernelGGL((project_mfma_kernel<T, V>), dim3(grid), dim3(kThreads), plds, ctx->stream, (const T*)d_x, n, \
+            hipLaunchKernelGGL((project_mfma_kernel<T, V, FIN>), dim3(grid), dim3(kThreads), plds, ctx->stream, (const T*)d_x, n, \
                                F, ld, d_mu, d_inv_sigma, d_mean2, d_w, d, ldw, d_y, ldy, bits);                \
         } while (0)
-        if (dtype == MSM_F32) { if (vec) MSM_PROJ(float, true); else MSM_PROJ(float, false); }
-        else { if (vec) MSM_PROJ(double, true); else MSM_PROJ(double, false); }
+        if (dtype == MSM_F32) { if (vec && finite) MSM_PROJ(float, true, true); else if (vec) MSM_PROJ(float, true, false); else MSM_PROJ(float, false, false); }
+        else { if (vec && finite) MSM_PROJ(double, true, true); else if (vec) MSM_PROJ(double, true, false); else MSM_PROJ(double, false, false); }
 #undef MSM_PROJ
         MSM_CHECK_LAUNCH(ctx);
         return MSM_OK;
@@ -509,6 +521,18 @@ msm_status msm_project(msm_ctx* ctx, const void* d_x, msm_dtype dtype, int64_t n
                            F, ld, d_mu, d_inv_sigma, d_mean2, d_w, d, ldw, d_y, ldy, bits);
     MSM_CHECK_LAUNCH(ctx);
     return MSM_OK;
+}
+
+msm_status msm_project(msm_ctx* ctx, const void* d_x, msm_dtype dtype, int64_t n, int F, int64_t ld,
+                       const double* d_mu, const double* d_inv_sigma, const double* d_mean2, const double* d_w, int d,
+                       int64_t ldw, double* d_y, int64_t ldy, double* d_absmax) {
+    return project_impl(ctx, d_x, dtype, n, F, ld, d_mu, d_inv_sigma, d_mean2, d_w, d, ldw, d_y, ldy, d_absmax, false);
+}
+
+msm_status msm_project_finite(msm_ctx* ctx, const void* d_x, msm_dtype dtype, int64_t n, int F, int64_t ld,
+                              const double* d_mu, const double* d_inv_sigma, const double* d_mean2, const double* d_w,
+                              int d, int64_t ldw, double* d_y, int64_t ldy, double* d_absmax) {
+    return project_impl(ctx, d_x, dtype, n, F, ld, d_mu, d_inv_sigma, d_mean2, d_w, d, ldw, d_y, ldy, d_absmax, true);
 }
 
 }  // extern "C"

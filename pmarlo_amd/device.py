@@ -474,14 +474,16 @@ class Engine:
 
     def project(self, x: DeviceArray, mu: DeviceArray, inv_sigma: DeviceArray, W: DeviceArray, d: int, *,
                 mean2: DeviceArray | None = None, out: DeviceArray | None = None,
-                absmax: DeviceArray | None = None) -> DeviceArray:
-        """`absmax` (one f64, e.g. slot 2 of a k-means fit state) receives max |Y| from the same pass."""
+                absmax: DeviceArray | None = None, assume_finite: bool = False) -> DeviceArray:
+        """`absmax` (one f64, e.g. slot 2 of a k-means fit state) receives max |Y| from the same pass.
+        assume_finite: X holds no NaN (column_moments' count tells); the per-element NaN test is left out."""
         n, F = x.shape
         ldw = W.shape[1]
         out = out if out is not None else self.empty((n, d), np.float64)
-        check(lib.msm_project(self.handle, x.ptr, _dtype_code(x.dtype), n, F, F, mu.ptr, inv_sigma.ptr,
-                              mean2.ptr if mean2 is not None else None, W.ptr, int(d), ldw, out.ptr,
-                              out.shape[1], absmax.ptr if absmax is not None else None), self.handle)
+        fn = lib.msm_project_finite if assume_finite else lib.msm_project
+        check(fn(self.handle, x.ptr, _dtype_code(x.dtype), n, F, F, mu.ptr, inv_sigma.ptr,
+                 mean2.ptr if mean2 is not None else None, W.ptr, int(d), ldw, out.ptr,
+                 out.shape[1], absmax.ptr if absmax is not None else None), self.handle)
         return out
 
     def eigh(self, a: DeviceArray, want_vectors: bool = True):

@@ -353,7 +353,7 @@ class ShardedMSM:
             # 3. projection; max |Y| (the fixed-point scale of the Lloyd sums needs it) falls out of the same pass
             # (x - shift) / sigma - m2: m2 is the symmetric mean about the SAME shift the moments used
             eng.project(self.x, b["shift"], self.inv_scale, self.W, d, mean2=self.m2, out=self.Y,
-                        absmax=b["fit_state"].view((1,), offset_elems=2))
+                        absmax=b["fit_state"].view((1,), offset_elems=2), assume_finite=True)
             self._stamp("project")
         # 4. k-means: fixed number of Lloyd iterations over all frames
         eng.kmeans_fit_begin(self.Y, k, seed=cfg.seed, n_total=self.n_total, tol2=0.0, centers=b["centers"],

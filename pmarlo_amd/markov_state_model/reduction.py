@@ -184,7 +184,7 @@ def tica_fit_transform_trajectories(features: np.ndarray, traj_lengths: Sequence
     mom = pipe.tica_moments(xd, lag, mu, segments=segs, assume_finite=not has_nan, symmetric=True)
     model = pipe.tica_solve(mom, mu, one, one, lag, n_components)
     model.dim = min(n_components, int(model.rank.to_host()[0]))
-    Y = pipe.tica_transform(model, xd).to_host()
+    Y = pipe.tica_transform(model, xd, assume_finite=not has_nan).to_host()
     keep: List[np.ndarray] = []
     for a, b in segs:
         keep.append(Y[a:b - drop] if b - a > drop else np.empty((0, Y.shape[1])))

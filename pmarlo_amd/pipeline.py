@@ -110,8 +110,10 @@ class MSMPipeline:
         eig, W, mean, rank = self.eng.tica_solve(moments, F, scale=sigma, epsilon=epsilon, kinetic_map=kinetic_map)
         return TicaModel(mu, sigma, inv_sigma, eig, W, mean, rank, int(lag), int(dim), moments)
 
-    def tica_transform(self, model: TicaModel, x: DeviceArray, out: DeviceArray | None = None) -> DeviceArray:
-        return self.eng.project(x, model.mu, model.inv_sigma, model.coefficients, model.dim, mean2=model.mean, out=out)
+    def tica_transform(self, model: TicaModel, x: DeviceArray, out: DeviceArray | None = None,
+                       assume_finite: bool = False) -> DeviceArray:
+        return self.eng.project(x, model.mu, model.inv_sigma, model.coefficients, model.dim, mean2=model.mean, out=out,
+                                assume_finite=assume_finite)
 
     # ---- clustering --------------------------------------------------------------
     def cluster(self, y: DeviceArray, k: int, *, seed: int = 0, max_iter: int = 50, tol: float = 1e-4,

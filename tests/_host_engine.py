@@ -119,7 +119,7 @@ class HostEngine:
         rank.a[...] = r
         return out
 
-    def project(self, x, mu, inv_sigma, W, d, *, mean2=None, out=None, absmax=None):
+    def project(self, x, mu, inv_sigma, W, d, *, mean2=None, out=None, absmax=None, assume_finite=False):
         z = (x.a.astype(np.float64) - mu.a) * inv_sigma.a
         if mean2 is not None:
             z = z - mean2.a

@@ -271,6 +271,23 @@ def test_project_matches_numpy(engine):
                        mean2=engine.to_device(m2)).to_host()
     want = ((X.astype(np.float64) - mu) * isg - m2) @ W[:, :d]
     np.testing.assert_allclose(Y, want, rtol=1e-12, atol=1e-12)
+    # the entry for NaN-free input leaves out a test, not arithmetic: the same bits; shapes off the vector path too
+    for dtype, Fx in [(np.float32, 64), (np.float64, 64), (np.float32, 48), (np.float32, 50)]:
+        Xd = engine.to_device(X[:, :Fx].astype(dtype))
+        args = (engine.to_device(mu[:Fx]), engine.to_device(isg[:Fx]), engine.to_device(np.ascontiguousarray(W[:Fx, :Fx])), d)
+        a = engine.project(Xd, *args, mean2=engine.to_device(m2[:Fx])).to_host()
+        b = engine.project(Xd, *args, mean2=engine.to_device(m2[:Fx]), assume_finite=True).to_host()
+        np.testing.assert_array_equal(a, b)
+        np.testing.assert_allclose(a, ((X[:, :Fx].astype(dtype).astype(np.float64) - mu[:Fx]) * isg[:Fx] - m2[:Fx]) @ W[:Fx, :d],
+                                   rtol=1e-12, atol=1e-12)
+    # NaN -> column mean (z = 0) on the plain entry
+    Xn = X.copy()
+    Xn[5, 3] = np.nan
+    Yn = engine.project(engine.to_device(Xn), engine.to_device(mu), engine.to_device(isg), engine.to_device(W), d,
+                        mean2=engine.to_device(m2)).to_host()
+    Xi = Xn.astype(np.float64)
+    Xi[5, 3] = mu[3]
+    np.testing.assert_allclose(Yn, ((Xi - mu) * isg - m2) @ W[:, :d], rtol=1e-12, atol=1e-12)
 
 
 @pytest.mark.parametrize("n,F,lag,dtype,segs", [
