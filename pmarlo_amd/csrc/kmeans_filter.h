@@ -345,7 +345,11 @@ __global__ __launch_bounds__(1024, 4) void kmeans_filter_kernel(
     __shared__ int tile_flag[64];
     {
         // padding tiles too (their rows carry the -inf sentinel); two tiles per trip, both fetched before either is built
+#ifdef MSM_KMF_DIAG_NOSTAGE   // timing experiment only: tables left unbuilt (wrong results)
+        for (int t = wave; t < 0; t += 2 * (kMT / 64)) {
+#else
         for (int t = wave; t < n_tiles; t += 2 * (kMT / 64)) {
+#endif
             const int t2 = t + kMT / 64;
             double c0[kStageRegs], c1[kStageRegs];
             filter_stage_fetch(t, lane, centers, k, d, c0);

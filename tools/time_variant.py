@@ -53,6 +53,8 @@ def main():
         img = eng.kmeans_pack(Y)
         med, mn = timeit(eng, lambda: eng.kmeans_assign(Y, cen, labels=lab, image=img))
         print(f"{sys.argv[1]:48s} kmeans assign: median {med * 1e3:8.1f} us  min {mn * 1e3:8.1f} us")
+        if sys.argv[1] != "-":
+            return   # diagnostic variants: the assign pass only
         # accumulate passes: full sums, then delta sums against labels that barely move
         cfg = ShardConfig(n_frames=n, n_features=F, tica_dim=d, k=k, lag=lag, kmeans_iters=10, seed=0, n_total=n)
         msm = ShardedMSM(eng, cfg, xd)
