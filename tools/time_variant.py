@@ -32,7 +32,7 @@ def timeit(eng, fn, reps=20, warm=3):
 
 def main():
     stage = sys.argv[2]
-    n, F, lag = (int(v) for v in (sys.argv[3:6] if len(sys.argv) > 5 else (1_000_000, 64, 10)))
+    n, F, lag = (int(v) for v in (sys.argv[3:6] if len(sys.argv) > 5 and sys.argv[3].isdigit() else (1_000_000, 64, 10)))
     eng = Engine(0)
     X = _gen.correlated_series(n, F, seed=1000)
     xd = eng.to_device(X)
@@ -53,8 +53,8 @@ def main():
         img = eng.kmeans_pack(Y)
         med, mn = timeit(eng, lambda: eng.kmeans_assign(Y, cen, labels=lab, image=img))
         print(f"{sys.argv[1]:48s} kmeans assign: median {med * 1e3:8.1f} us  min {mn * 1e3:8.1f} us")
-        if sys.argv[1] != "-":
-            return   # diagnostic variants: the assign pass only
+        if sys.argv[1] != "-" and "full" not in sys.argv:
+            return   # diagnostic variants: the assign pass only (append `full` for the accumulate passes)
         # accumulate passes: full sums, then delta sums against labels that barely move
         cfg = ShardConfig(n_frames=n, n_features=F, tica_dim=d, k=k, lag=lag, kmeans_iters=10, seed=0, n_total=n)
         msm = ShardedMSM(eng, cfg, xd)
