@@ -73,16 +73,21 @@ __global__ __launch_bounds__(kThreads) void count_lds_kernel(
             ++local_pairs;
         }
     };
+#ifdef MSM_COUNTS_UNROLL
+    constexpr int kU = MSM_COUNTS_UNROLL;
+#else
+    constexpr int kU = 4;
+#endif
     int64_t p = p0 + tid;
-    for (; p + 3 * kThreads < p1; p += 4 * kThreads) {  // 8 independent loads in flight per lane
-        int64_t t[4];
-        int a[4], b[4];
+    for (; p + (kU - 1) * kThreads < p1; p += kU * kThreads) {  // 2 kU independent loads in flight per lane
+        int64_t t[kU];
+        int a[kU], b[kU];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) t[u] = seg_pair_to_frame(st, p + u * kThreads);
+        for (int u = 0; u < kU; ++u) t[u] = seg_pair_to_frame(st, p + u * kThreads);
 #pragma unroll
-        for (int u = 0; u < 4; ++u) { a[u] = labels[t[u]]; b[u] = labels[t[u] + lag]; }
+        for (int u = 0; u < kU; ++u) { a[u] = labels[t[u]]; b[u] = labels[t[u] + lag]; }
 #pragma unroll
-        for (int u = 0; u < 4; ++u) bin_pair(a[u], b[u], t[u]);
+        for (int u = 0; u < kU; ++u) bin_pair(a[u], b[u], t[u]);
     }
     for (; p < p1; p += kThreads) {
         const int64_t t = seg_pair_to_frame(st, p);
@@ -90,10 +95,12 @@ __global__ __launch_bounds__(kThreads) void count_lds_kernel(
     }
     __syncthreads();
     out_t* dst = counts + (size_t)r0 * k;
+#ifndef MSM_COUNTS_DIAG_NOFLUSH   // timing experiment only
     for (int i = tid; i < nbins; i += kThreads) {
         const lds_t v = bins[i];
         if (v != (lds_t)0) atomicAdd(&dst[i], (out_t)v);
     }
+#endif
     if (pairs_out) block_add_u64(local_pairs, pairs_out);
 }
 

@@ -70,6 +70,13 @@ def main():
         med, mn = timeit(eng, lambda: eng.kmeans_accumulate(msm.Y, msm.buf["centers"], st, sums, counts, image=img2, prev_labels=prev))
         print(f"{sys.argv[1]:48s} kmeans accumulate (delta, nothing moves): median {med * 1e3:8.1f} us  min {mn * 1e3:8.1f} us")
         return
+    elif stage == "counts":   # lag-tau transition counts of Markov-chain labels, k = 500
+        k = 500
+        lab = eng.to_device(_gen.markov_labels(n, k, 3))
+        eng.count_transitions(lab, k, lag)
+        med, mn = timeit(eng, lambda: eng.count_transitions(lab, k, lag))
+        print(f"{sys.argv[1]:48s} counts: median {med * 1e3:8.1f} us  min {mn * 1e3:8.1f} us")
+        return
     else:
         raise SystemExit("stage?")
     print(f"{sys.argv[1]:48s} {stage}: median {med * 1e3:8.1f} us  min {mn * 1e3:8.1f} us  checksum {float(np.abs(mom.to_host()).sum()):.17g}")
