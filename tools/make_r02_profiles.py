@@ -47,7 +47,7 @@ def main():
             "overlap on this chip.", ""]
     (P / "r02_pmc.md").write_text("\n".join(head) + table)
     alg = {"kmeans_filter_kernel<double, 2, 4, true, false>": 208, "kmeans_filter_kernel<double, 2, 4, false, false>": 212,
-           "cov_fused_kernel<float, 4, true, true, true, true>": 256, "cov_fused_kernel<float, 4, true, true, true>": 256, "project_mfma_kernel<float, true>": 336,
+           "cov_fused_kernel<float, 4, true, true, true, true>": 256, "cov_fused_kernel<float, 4, true, true, true>": 256, "project_mfma_kernel<float, true>": 336, "project_mfma_kernel<float, true, true>": 336,
            "kmeans_pack_kernel<double, 10>": 208, "count_lds_kernel<false>": 4, "moments_partial_kernel<float>": 256}
     rows = [(k, v["dispatches"], v["FETCH_SIZE"], v["WRITE_SIZE"], (2 * v["FETCH_SIZE"] + v["WRITE_SIZE"]) * 1024 / 1e6)
             for k, v in d.items() if v.get("FETCH_SIZE") is not None and v.get("WRITE_SIZE") is not None]
