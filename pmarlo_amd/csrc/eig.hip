@@ -531,7 +531,7 @@ struct TriShared {
     double part[16][kTriMax];  // partial products of the tridiagonalisation, one row per wave (the LDL' phase uses rows 0-7)
     union {                    // the two register-resident phases never overlap
         double2 vw[8][kTriMax];                 // tridiagonalisation: {v_j, w_j} of the column in flight, one copy per A wave
-        alignas(16) double lv[12][kTriMax];     // LDL': multipliers of the column in flight, one copy per working wave
+        alignas(16) double lv[16][kTriMax];     // LDL': multipliers of the column in flight, one copy per working wave
     };
     double vpub[2][kTriMax];   // tridiagonalisation: the reflector of column k for the Q' waves, slot k & 1
     double taupub[2];
@@ -842,32 +842,32 @@ __device__ __forceinline__ void householder_phase(double* A, double* QT, int n, 
     }
 }
 
-// Whitening of a full-rank C00 in registers, the pattern of householder_phase: two LDL' eliminations side by side, one
-// barrier per column.  Waves 0-3 hold the rows i = w (mod 4) of C00, waves 4-7 the same rows of X (= identity at the
-// start), waves 8-11 those of the probe C00 - epsilon I; lane = column; 16 doubles per lane, compile-time indices only.
+// Whitening of a full-rank C00 in registers, the pattern of householder_phase: an LDL' elimination with X = L^-1 carried
+// along, one barrier per column.  Waves 0-7 hold the rows i = w (mod 8) of C00, waves 8-15 the same rows of X (= identity
+// at the start); lane = column; 8 doubles per lane, compile-time indices only.
 // Column j: the owner of row j has left it in the LDS.  The trailing matrix is symmetric, so that row is also column j:
 // lane i of (row j) / d_j IS the multiplier l_i; every wave parks the multipliers in its own LDS copy, ordered so that
-// those of its sixteen rows come back as eight 16-byte broadcast reads.  Row i of M, X or the probe then takes one fma
-// (l_i = 0 up to row j: finished rows stay); the owner of row j + 1 leaves it in the LDS for the next column.  The SIMDs
-// issue about one instruction per 3.3-3.8 cycles between all their waves, so what counts per column is the instruction
-// total: 1.5 per row here.
+// those of its eight rows come back as four 16-byte broadcast reads.  Row i of C00 or X then takes one fma (l_i = 0 up
+// to row j: finished rows stay); the owner of row j + 1 leaves it in the LDS for the next column.  A wave issues about
+// one instruction per 10 cycles, so the column's chain is kept short by dealing the rows over all sixteen waves.
 // On success W = (D^-1/2 L^-1)' (upper triangular, W' C00 W = I) is written to `W`; false (uniformly) as soon as a pivot
-// of either matrix is not positive.  C is left as it was.  blockDim.x >= 768.
-// mode 0: both eliminations; 1: C00 and X only (the caller certifies full rank from W, see tica_solve_kernel);
-// 2: the probe alone (waves 0-3), nothing is written to W.
+// is not positive.  C is left as it was.  blockDim.x == 1024.
+// mode 1: C00 and X (the caller certifies full rank from W, see tica_solve_kernel);
+// mode 2: the probe C00 - epsilon I alone (waves 0-7), nothing is written to W.
 __device__ __forceinline__ bool ldl_whiten_registers(const double* C, double* W, int n, double epsilon, TriShared* ts,
                                                      int mode) {
+    static_assert(kEigThreads == 1024, "ldl_whiten_registers deals the rows over sixteen waves");
     constexpr int ld = kTriLd;
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const bool in = lane < n;
     // 0: C00, 1: X, 2: probe, 3: nothing
-    const int what = mode == 2 ? (wave < 4 ? 2 : 3) : (mode == 1 ? (wave < 8 ? wave >> 2 : 3) : wave >> 2);
-    const bool both = mode == 0;
-    const int sub = wave & 3;
-    double m[16];
+    const int what = mode == 2 ? (wave < 8 ? 2 : 3) : (wave < 8 ? 0 : 1);
+    const int src = mode == 2 ? 2 : 0;   // the matrix the multipliers come from: its published rows sit in part[par + src]
+    const int sub = wave & 7;
+    double m[8];
 #pragma unroll
-    for (int t = 0; t < 16; ++t) {
-        const int i = sub + 4 * t;
+    for (int t = 0; t < 8; ++t) {
+        const int i = sub + 8 * t;
         if (what == 1) m[t] = lane == i ? 1.0 : 0.0;
         else m[t] = (what < 3 && in && i < n) ? C[i * ld + lane] - (what == 2 && lane == i ? epsilon : 0.0) : 0.0;
     }
@@ -877,42 +877,37 @@ __device__ __forceinline__ bool ldl_whiten_registers(const double* C, double* W,
     for (int j = 0; j < n; ++j) {
         const int par = (j & 1) * 4;
         if (what < 3) {
-            // row j of the matrix the multipliers come from, of the matrix this wave updates, and of the other
-            // elimination: every wave sees both pivots, so all of them leave together when one is not positive
-            const double rowM = ts->part[par + (what == 2 ? 2 : 0)][lane];
+            // row j of the matrix the multipliers come from and of the matrix this wave updates
+            const double rowM = ts->part[par + src][lane];
             const double row = what == 1 ? ts->part[par + 1][lane] : rowM;
-            const double rowO = both ? ts->part[par + (what == 2 ? 0 : 2)][lane] : 1.0;
-            const double d = bcast_lane(rowM, j), dO = both ? bcast_lane(rowO, j) : 1.0;
+            const double d = bcast_lane(rowM, j);
             LSTAMP(13);
-            if (!(d > 0.0) || !(dO > 0.0)) return false;   // uniform over the workgroup (see below for the idle waves)
+            if (!(d > 0.0)) return false;   // uniform over the workgroup (see below for the idle waves)
             {
                 // multipliers of the live rows (zero up to row j: finished rows stay as they are), dealt out so that
-                // the sixteen of this wave's rows lie side by side in its LDS copy: l_i at (i mod 4) * 16 + i / 4
+                // the eight of this wave's rows lie side by side in its LDS copy: l_i at (i mod 8) * 8 + i / 8
                 const double lvec = lane > j ? rowM * nr_rcp(d) : 0.0;
                 double* lv = ts->lv[wave];
-                lv[(lane & 3) * 16 + (lane >> 2)] = lvec;
-                const double2* mine = reinterpret_cast<const double2*>(lv + sub * 16);
+                lv[(lane & 7) * 8 + (lane >> 3)] = lvec;
+                const double2* mine = reinterpret_cast<const double2*>(lv + sub * 8);
 #pragma unroll
-                for (int t2 = 0; t2 < 8; ++t2) {
+                for (int t2 = 0; t2 < 4; ++t2) {
                     const double2 l = mine[t2];
                     m[2 * t2] = fma(-l.x, row, m[2 * t2]);
                     m[2 * t2 + 1] = fma(-l.y, row, m[2 * t2 + 1]);
                 }
-                if (((j + 1 - sub) & 3) == 0) {   // this wave owns row j + 1: leave it for the next column
+                if (((j + 1 - sub) & 7) == 0) {   // this wave owns row j + 1: leave it for the next column
                     double* dst = ts->part[(par ^ 4) + what] + lane;
-                    switch ((j + 1 - sub) >> 2) {
+                    switch ((j + 1 - sub) >> 3) {
                         case 0: *dst = m[0]; break;   case 1: *dst = m[1]; break;   case 2: *dst = m[2]; break;
                         case 3: *dst = m[3]; break;   case 4: *dst = m[4]; break;   case 5: *dst = m[5]; break;
-                        case 6: *dst = m[6]; break;   case 7: *dst = m[7]; break;   case 8: *dst = m[8]; break;
-                        case 9: *dst = m[9]; break;   case 10: *dst = m[10]; break; case 11: *dst = m[11]; break;
-                        case 12: *dst = m[12]; break; case 13: *dst = m[13]; break; case 14: *dst = m[14]; break;
-                        case 15: *dst = m[15]; break; default: break;
+                        case 6: *dst = m[6]; break;   case 7: *dst = m[7]; break;   default: break;
                     }
                 }
             }
-        } else {   // waves without rows: the same two pivots, the same decision
-            const double dM = mode == 2 ? 1.0 : ts->part[par][j], dP = mode == 1 ? 1.0 : ts->part[par + 2][j];
-            if (!(dM > 0.0) || !(dP > 0.0)) return false;
+        } else {   // waves without rows: the same pivot, the same decision
+            const double dP = ts->part[par + src][j];
+            if (!(dP > 0.0)) return false;
         }
         LSTAMP(14);
         __syncthreads();
@@ -921,14 +916,14 @@ __device__ __forceinline__ bool ldl_whiten_registers(const double* C, double* W,
     // d_i sits in lane i of row i of the C00 waves (row i was final after column i - 1): hand D^-1/2 to the X waves
     if (what == 0) {
 #pragma unroll
-        for (int t = 0; t < 16; ++t)
-            if (lane == sub + 4 * t && lane < n) ts->inv[lane] = nr_rsqrt(m[t]);
+        for (int t = 0; t < 8; ++t)
+            if (lane == sub + 8 * t && lane < n) ts->inv[lane] = nr_rsqrt(m[t]);
     }
     __syncthreads();
     if (what == 1 && in) {
 #pragma unroll
-        for (int t = 0; t < 16; ++t) {
-            const int i = sub + 4 * t;
+        for (int t = 0; t < 8; ++t) {
+            const int i = sub + 8 * t;
             if (i < n) W[lane * ld + i] = m[t] * ts->inv[i];   // X is lower triangular: zeros above the diagonal of W'
         }
     }
