@@ -670,14 +670,15 @@ __device__ __forceinline__ int sturm_count(const TriShared* ts, int nblocks, dou
 // Here nothing is swept and the per-wave instruction chain of a column is kept short:
 //   waves 0-7 hold the rows j = w (mod 8) of A for the whole reduction, waves 8-15 the same rows of Q'
 //   (QT[j][r] = Q[r][j]): 8 doubles per lane, indexed by compile-time constants only (lane = column);
-//   A waves, column k:
-//   (1) read row k (left in the LDS by its owner one column earlier) and form the reflector, every A wave for itself
-//       (same inputs, same instructions, same bits): x = A[k][k+1:], H = I - tau v v', v_{k+1} = 1; wave 0 also leaves
-//       v and tau in the LDS for the Q' waves;
-//   (2) partial product p = A22 v over the own rows (the v_j come back as broadcast reads of the wave's own LDS copy);
+//   A waves, column k (the reflector of column 0 is formed ahead of the loop):
+//   (1) partial product p = A22 v over the own rows (the v_j come back as broadcast reads of the wave's own LDS copy);
 //       barrier 1;
-//   (3) the eight partials are summed in a fixed order, w = tau p - (tau^2 p.v / 2) v, a_j -= v_j w + w_j v on the own
-//       rows, the owner of row k + 1 leaving it in the LDS; barrier 2.
+//   (2) the eight partials are summed in a fixed order, w = tau p - (tau^2 p.v / 2) v; the owner of row k + 1 puts the
+//       new value of that row in the LDS at once; barrier 2;
+//   (3) a_j -= v_j w + w_j v on the own rows and, in the same straight-line stretch, the reflector of column k + 1
+//       from row k + 1, every A wave for itself (same inputs, same instructions, same bits): x = A[k+1][k+2:],
+//       H = I - tau v v', v_{k+2} = 1; wave 0 also leaves v and tau in the LDS for the Q' waves.  A column that is
+//       already reduced gives tau = 0 and everything downstream of it is arithmetic with zeros: no branches.
 //   Q' waves run half a column behind and never form a reflector: between barrier 1 and 2 of column k they read v_k and
 //   write their partial u = Q v; between barrier 2 and barrier 1 of the next column they sum the partials and apply
 //   q_j -= tau v_j u.  They add nothing to the A waves' chain, which is what a column costs.
@@ -750,76 +751,87 @@ __device__ __forceinline__ void householder_phase(double* A, double* QT, int n, 
             });
         }
     };
+    // reflector of column c from row c in the LDS (straight-line: a column that is already reduced gives tau = 0, v = e_{c+1},
+    // and everything downstream of it is a no-op); wave 0 also records d_c, e_c and leaves v, tau for the Q' waves
+    auto reflector = [&](int c, double& vi, double& tau) {
+        const double* rowc = A + c * ld;
+        double xi = rowc[in ? lane : 0];
+        const double alpha = rowc[c + 1];
+        if (wave == 0 && lane == c) ts->d[c] = xi;
+        const bool actc = in && lane > c;
+        if (!actc) xi = 0.0;
+        const double sigma = wave_sum_all(lane > c + 1 ? xi * xi : 0.0);
+        const bool nz = sigma != 0.0;   // the same in every lane
+        const double h2 = fma(alpha, alpha, sigma);
+        const double rs = nr_rsqrt(nz ? h2 : 1.0);
+        const double beta = nz ? -copysign(h2 * rs, alpha) : alpha;
+        tau = nz ? (beta - alpha) * -copysign(rs, alpha) : 0.0;   // (beta - alpha) / beta
+        const double scal = nr_rcp(nz ? alpha - beta : 1.0);
+        vi = actc ? (lane == c + 1 ? 1.0 : (nz ? xi * scal : 0.0)) : 0.0;
+        if (wave == 0) {
+            ts->vpub[c & 1][lane] = vi;
+            if (lane == 0) { ts->e[c] = beta; ts->taupub[c & 1] = tau; }
+        }
+        vw[lane].x = vi;
+    };
     LSTAMP_INIT
+    double vi = 0.0, tau = 0.0;
+    if (is_a && n > 2) reflector(0, vi, tau);
     for (int k = 0; k + 2 < n; ++k) {
         LSTAMP(16);
-        double vi = 0.0, tau = 0.0;
         const bool act = in && lane > k;
         if (is_a) {
-            const double* rowk = A + k * ld;
-            double xi = rowk[in ? lane : 0];
-            const double alpha = rowk[k + 1];
-            if (wave == 0 && lane == k) ts->d[k] = xi;
-            if (!act) xi = 0.0;
-            const double sigma = wave_sum_all(lane > k + 1 ? xi * xi : 0.0);
-            double beta = alpha, scal = 0.0;
-            if (__builtin_amdgcn_readfirstlane(sigma != 0.0)) {   // every lane holds the same sigma
-                const double h2 = fma(alpha, alpha, sigma);
-                const double rs = nr_rsqrt(h2);
-                beta = -copysign(h2 * rs, alpha);
-                tau = (beta - alpha) * -copysign(rs, alpha);   // (beta - alpha) / beta
-                scal = nr_rcp(alpha - beta);
-            }
-            vi = act ? (lane == k + 1 ? 1.0 : xi * scal) : 0.0;
-            if (wave == 0) {
-                ts->vpub[k & 1][lane] = vi;
-                if (lane == 0) { ts->e[k] = beta; ts->taupub[k & 1] = tau; }
-            }
-            LSTAMP(17);
-            if (__builtin_amdgcn_readfirstlane(tau != 0.0)) {
-                vw[lane].x = vi;
-                double s0 = 0.0, s1 = 0.0;
-                hh_for_groups(sub, k, [&](int g) {
-                    double v[4];
+            // partial product p = A22 v over the own rows
+            double s0 = 0.0, s1 = 0.0;
+            hh_for_groups(sub, k, [&](int g) {
+                double v[4];
 #pragma unroll
-                    for (int u = 0; u < 4; ++u) v[u] = vw[sub + 32 * g + 8 * u].x;
-                    s0 = fma(m[4 * g], v[0], s0);
-                    s1 = fma(m[4 * g + 1], v[1], s1);
-                    s0 = fma(m[4 * g + 2], v[2], s0);
-                    s1 = fma(m[4 * g + 3], v[3], s1);
-                });
-                part[lane] = s0 + s1;
-            }
+                for (int u = 0; u < 4; ++u) v[u] = vw[sub + 32 * g + 8 * u].x;
+                s0 = fma(m[4 * g], v[0], s0);
+                s1 = fma(m[4 * g + 1], v[1], s1);
+                s0 = fma(m[4 * g + 2], v[2], s0);
+                s1 = fma(m[4 * g + 3], v[3], s1);
+            });
+            part[lane] = s0 + s1;
             LSTAMP(18);
         } else if (is_q && k > 0) {
             q_finish(k - 1);
         }
         __syncthreads();
         LSTAMP(19);
+        double wi = 0.0;
         if (is_a) {
-            if (__builtin_amdgcn_readfirstlane(tau != 0.0)) {
-                const double p = sum_parts();
-                const double pv = wave_sum_all(act ? p * vi : 0.0);
-                const double al = -0.5 * tau * (tau * pv);
-                const double wi = act ? fma(tau, p, al * vi) : 0.0;
-                vw[lane].y = wi;
-                LSTAMP(20);
-                hh_for_groups(sub, k, [&](int g) {
-                    double2 b[4];
+            const double p = sum_parts();
+            const double pv = wave_sum_all(act ? p * vi : 0.0);
+            const double al = -0.5 * tau * (tau * pv);
+            wi = act ? fma(tau, p, al * vi) : 0.0;
+            vw[lane].y = wi;
+            LSTAMP(20);
+            // the owner of row k + 1 leaves its new value in the LDS ahead of the rest of the update: everybody's next
+            // reflector hangs on it (the same two fmas again below: the same bits)
 #pragma unroll
-                    for (int u = 0; u < 4; ++u) b[u] = vw[sub + 32 * g + 8 * u];
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        m[4 * g + u] = fma(-wi, b[u].x, fma(-vi, b[u].y, m[4 * g + u]));
-                        if (in && sub + 32 * g + 8 * u == k + 1) A[(k + 1) * ld + lane] = m[4 * g + u];   // next column's x
-                    }
-                });
-            }
+            for (int t2 = 0; t2 < 8; ++t2)
+                if (sub + 8 * t2 == k + 1) {
+                    const double2 bk = vw[k + 1];
+                    if (in) A[(k + 1) * ld + lane] = fma(-wi, bk.x, fma(-vi, bk.y, m[t2]));
+                }
         } else if (is_q) {
             q_partial(k);
         }
         LSTAMP(21);
         __syncthreads();
+        if (is_a) {
+            // rank-2 update of the own rows (rows up to k carry v_j = w_j = 0: untouched) and, in the same straight-line
+            // stretch, the reflector of the next column: two independent chains for the scheduler to interleave
+            double2 bb[8];
+#pragma unroll
+            for (int t2 = 0; t2 < 8; ++t2) bb[t2] = vw[sub + 8 * t2];
+            const double vk = vi, wk = wi;
+            if (k + 3 < n) reflector(k + 1, vi, tau);
+#pragma unroll
+            for (int t2 = 0; t2 < 8; ++t2) m[t2] = fma(-wk, bb[t2].x, fma(-vk, bb[t2].y, m[t2]));
+            LSTAMP(17);
+        }
     }
     if (is_q && n > 2) q_finish(n - 3);
     // back to the LDS: Q' whole, of A the last two rows (the 2 x 2 block the reduction leaves)

@@ -10,7 +10,7 @@ static const char* names[24] = {"init Q", "Householder columns", "barrier", "ext
                                 "multisection", "twisted factorisation vectors", "residual + orthogonality check", "Z = Q X",
                                 "tica: covariances from moments", "tica: LDL' + inverse (or eigen path)", "tica: Ct = L' C0t L",
                                 "tica: eigensolve (sum of the rows above)", "tica: sort, R = L Z, signs, output", "  ldl: pivots, reciprocals", "  ldl: updates", "  ldl: barrier",
-                                "  hh: barrier 2 + loop top", "  hh: x, sigma, reflector", "  hh: partial p = A v", "  hh: barrier 1", "  hh: sum partials, p.v, w", "  hh: rank-2 update of the own rows", "", ""};
+                                "  hh: loop top", "  hh: barrier 2, rank-2 update + next reflector", "  hh: partial p = A v", "  hh: barrier 1", "  hh: sum partials, p.v, w", "  hh: row k+1 published", "", ""};
 static void report(const char* what, float ms) {
     unsigned long long st[24];
     hipMemcpyFromSymbol(st, HIP_SYMBOL(g_tri_stamps), sizeof(st));
