@@ -871,15 +871,8 @@ bool filter_enabled() {
     return on;
 }
 
-int filter_stagger() {
-    static const int v = [] {
-        const char* e = getenv("MSM_KMEANS_STAGGER");   // start offset between the waves of a SIMD, units of 512 cycles
-        return e ? atoi(e) : 0;   // measured: no effect (tools/run/kmf.sh sweep), kept as a diagnostic knob
-    }();
-    return v;
-}
-
-size_t filter_image_bytes(int64_t n, int d) { return (size_t)n * 64 * filter_nm(d); }
+// whole units of 64 rows (the filter kernel loads a unit without clamping)
+size_t filter_image_bytes(int64_t n, int d) { return (size_t)((n + 63) & ~(int64_t)63) * 16 * filter_rowq(filter_nm(d)); }
 
 template <typename T>
 msm_status launch_pack(msm_ctx* ctx, const T* x, int64_t n, int d, int64_t ld, const double* mean, const double* stdv,
@@ -922,15 +915,16 @@ msm_status launch_filter_nm(msm_ctx* ctx, const T* x, int64_t n, int d, int64_t 
     // (the centre tables are built by every workgroup of the kernel for itself: no staging launch)
     msm_status rs;
     const int64_t n_units = (n + 16 * NF - 1) / (16 * NF);
-    const int grid = (int)std::min<int64_t>((n_units + 15) / 16, (int64_t)ctx->n_cu);
+    constexpr int kWaves = filter_waves(NM);
+    const int grid = (int)std::min<int64_t>((n_units + kWaves - 1) / kWaves, (int64_t)ctx->n_cu);
     unsigned long long* stats = nullptr;
     rs = filter_stats_buffer(ctx, &stats);
     if (rs != MSM_OK) return rs;
     auto kern = mean ? kmeans_filter_kernel<T, NM, NF, ACCUM, true> : kmeans_filter_kernel<T, NM, NF, ACCUM, false>;
     if (lds > 48 * 1024)
         MSM_HIP(ctx, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(1024), lds, ctx->stream, x, n, d, ld, k, mean, stdv, image, centers, labels,
-                       mindist, st, sums, counts, stats, filter_stagger());
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * kWaves), lds, ctx->stream, x, n, d, ld, k, mean, stdv, image, centers,
+                       labels, mindist, st, sums, counts, stats);
     MSM_CHECK_LAUNCH(ctx);
     return MSM_OK;
 }

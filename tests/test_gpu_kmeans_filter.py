@@ -76,8 +76,9 @@ def test_near_ties_and_duplicates(engine):
 
 
 def test_out_of_range_and_non_finite_frames(engine):
-    """NaN, inf, huge, tiny and zero coordinates: outside the range the filter's bounds hold for, so the frame
-    (or, for a bad centre, every frame) takes the exhaustive scan; labels stay those of the fp64 arithmetic."""
+    """NaN, inf, huge, tiny and zero coordinates.  Tiny ones (0 < |v| < 1e-14) stay out of the bf16 images and are paid
+    for in the bound; huge / non-finite ones send the frame (for a centre: every frame) to the exhaustive scan; labels stay
+    those of the fp64 arithmetic."""
     rng = np.random.default_rng(9)
     n, d, k = 5000, 6, 64
     X = rng.normal(size=(n, d))
@@ -94,11 +95,25 @@ def test_out_of_range_and_non_finite_frames(engine):
     centers = rng.normal(size=(k, d))
     _check(engine, X, centers)
     c2 = centers.copy()
-    c2[5, 1] = 1e-20                       # a centre outside the range: everything is scanned
+    c2[5, 1] = 1e-20                       # tiny centre coordinates: left out of the filter, covered by its bound
+    c2[6, 0] = -3e-15
     c2[9] = 0.0
     engine.kmeans_filter_scanned(reset=True)
     _check(engine, X, c2)
-    assert engine.kmeans_filter_scanned() >= 2 * n
+    assert engine.kmeans_filter_scanned() < 0.2 * 2 * n
+    Xt = X.copy()
+    Xt[:, 3] *= 1e-17                      # a whole feature at round-off level (a centred constant column)
+    c2[:, 3] *= 1e-17
+    engine.kmeans_filter_scanned(reset=True)
+    _check(engine, Xt, c2)
+    assert engine.kmeans_filter_scanned() < 0.2 * 2 * n
+    c4 = centers.copy()
+    c4[5, 1] = 1e19                        # a centre outside the range: everything is scanned
+    engine.kmeans_filter_scanned(reset=True)
+    _check(engine, X, c4)
+    assert engine.kmeans_filter_scanned() >= 2 * (n - 20)
+    c4[5, 1] = np.nan
+    _check(engine, X, c4)
     c3 = centers * 1e17                    # inside the range, products near the top of fp32
     _check(engine, X * 1e17, c3)
     _check(engine, X * 1e-13, centers * 1e-13)

@@ -40,7 +40,7 @@ int main(int argc, char** argv) {
     unsigned long long st[8];
     hipMemcpyFromSymbol(st, HIP_SYMBOL(g_km_stamps), sizeof(st));
     uint64_t scanned = 0; msm_kmeans_filter_scanned(ctx, &scanned, 0);
-    const char* names[] = {"centre tables built into the LDS", "image loads (drained)", "tile loop", "cross-lane: holder, pair, R", "frame loads + eight candidates re-scored", "commit (LDS atomics, labels)", "exhaustive scans", "exit + flush"};
+    const char* names[] = {"centre tables built into the LDS", "image loads (drained)", "tile loop", "next loads out, cross-lane: holder, pair, R", "coordinates in, candidate pick", "commit (LDS atomics, labels)", "step 4 (fp32 scan of all centres, band in fp64)", "exit + flush"};
     unsigned long long tot = 0; for (int i = 0; i < 8; ++i) tot += st[i];
     printf("n=%lld d=%d k=%d kernel %.3f ms (stamp build); scanned %llu frames in 3 passes; stamps are sums over the blocks (wave 0)\n", (long long)n, d, k, ms, (unsigned long long)scanned);
     for (int i = 0; i < 8; ++i) printf("%-28s %12llu ticks  %5.1f%%  per block %.0f\n", names[i], st[i], 100.0 * st[i] / tot, st[i] / 256.0);
