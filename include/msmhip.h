@@ -425,6 +425,12 @@ msm_status msm_kmeans_accumulate_delta(msm_ctx* ctx, const void* d_x, msm_dtype 
                                        const double* d_std, const void* d_image, const double* d_state,
                                        int32_t* d_prev_labels, int64_t* d_sums, int64_t* d_counts);
 msm_status msm_kmeans_filter_scanned(msm_ctx* ctx, uint64_t* h_out, int reset);
+/* Hardware rule the filter's certificate rests on (kmeans_filter.h, step 1): n_tiles independent
+ * v_mfma_f32_16x16x32_bf16 instructions, D = A B + C with A [16][32], B [32][16] bf16 (row major, raw 16-bit
+ * patterns) and C, D [16][16] f32, all HOST arrays.  tests/test_gpu_mfma_rule.py checks the accumulation
+ * bound, the irrelevance of the slot order and the treatment of small terms on every box the suite runs on. */
+msm_status msm_mfma_bf16_probe(msm_ctx* ctx, const uint16_t* h_a, const uint16_t* h_b, const float* h_c,
+                               float* h_d, int n_tiles);
 
 /* d_out[0] = sum of d_v[0..n) with a fixed-order two-level reduction (inertia =
  * sum of msm_kmeans_assign's d_mindist; clustering.py:391-392). */
@@ -672,6 +678,9 @@ msm_status msm_comm_init(msm_ctx* ctx, int rank, int world, const void* id, size
 void msm_comm_destroy(msm_comm* comm);
 msm_status msm_comm_info(msm_comm* comm, int* rank, int* world, uint64_t* n_collectives);
 msm_status msm_allreduce_i64(msm_comm* comm, int64_t* d_buf, size_t count);
+/* the same sum out of place: d_dst = sum over ranks of d_src (the persistent local member sums of the Lloyd passes
+ * are reduced straight into the exchange buffer, no copy in front of the collective) */
+msm_status msm_allreduce_i64_from(msm_comm* comm, const int64_t* d_src, int64_t* d_dst, size_t count);
 msm_status msm_allreduce_f64(msm_comm* comm, double* d_buf, size_t count);
 msm_status msm_allreduce_min_f64(msm_comm* comm, double* d_buf, size_t count);
 msm_status msm_allreduce_max_f64(msm_comm* comm, double* d_buf, size_t count);

@@ -88,6 +88,7 @@ _PROTOTYPES: dict[str, tuple] = {
     "msm_comm_destroy": (None, [_vp]),
     "msm_comm_info": (_i32, [_vp, C.POINTER(_i32), C.POINTER(_i32), C.POINTER(C.c_uint64)]),
     "msm_allreduce_i64": (_i32, [_vp, _vp, _sz]),
+    "msm_allreduce_i64_from": (_i32, [_vp, _vp, _vp, _sz]),
     "msm_allreduce_f64": (_i32, [_vp, _vp, _sz]),
     "msm_allreduce_min_f64": (_i32, [_vp, _vp, _sz]),
     "msm_allreduce_max_f64": (_i32, [_vp, _vp, _sz]),
@@ -100,6 +101,7 @@ _PROTOTYPES: dict[str, tuple] = {
     "msm_kmeans_accumulate_delta": (_i32, [_vp, _vp, _i32, _i64, _i32, _i64, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp,
                                            _vp]),
     "msm_kmeans_filter_scanned": (_i32, [_vp, C.POINTER(C.c_uint64), _i32]),
+    "msm_mfma_bf16_probe": (_i32, [_vp, _vp, _vp, _vp, _vp, _i32]),
     "msm_run_lengths": (_i32, [_vp, _vp, _i64, _i32, _vp, _vp, _vp, _i64, _vp]),
     "msm_sum_f64": (_i32, [_vp, _vp, _i64, _vp]),
     "msm_transition_matrix": (_i32, [_vp, _vp, _i32, _i32, _i32, _f64, _f64, _vp, _vp, _vp, _vp, _vp, _vp]),

@@ -152,6 +152,15 @@ msm_status msm_allreduce_i64(msm_comm* c, int64_t* d_buf, size_t count) {
     return MSM_OK;
 }
 
+msm_status msm_allreduce_i64_from(msm_comm* c, const int64_t* d_src, int64_t* d_dst, size_t count) {
+    if (!c) return MSM_ERR_INVALID;
+    MSM_REQUIRE(c->ctx, (d_src && d_dst) || count == 0, "msm_allreduce_i64_from: NULL buffer");
+    if (count == 0) return MSM_OK;
+    MSM_NCCL(c->ctx, rccl().AllReduce(d_src, d_dst, count, ncclInt64, ncclSum, c->comm, c->ctx->stream));
+    ++c->n_collectives;
+    return MSM_OK;
+}
+
 msm_status msm_allreduce_f64(msm_comm* c, double* d_buf, size_t count) {
     if (!c) return MSM_ERR_INVALID;
     msm_ctx* ctx = c->ctx;

@@ -862,6 +862,25 @@ msm_status launch_mfma(msm_ctx* ctx, const T* x, int64_t n, int d, int64_t ld, c
     return MSM_OK;
 }
 
+// one v_mfma_f32_16x16x32_bf16 per workgroup on operands given element by element (msm_mfma_bf16_probe)
+__global__ void mfma_bf16_probe_kernel(const uint16_t* __restrict__ A, const uint16_t* __restrict__ B,
+                                       const float* __restrict__ C, float* __restrict__ D) {
+    const int l = threadIdx.x, i = l & 15, q = l >> 4;
+    A += (size_t)blockIdx.x * 512;
+    B += (size_t)blockIdx.x * 512;
+    C += (size_t)blockIdx.x * 256;
+    D += (size_t)blockIdx.x * 256;
+    v8bf a, b;
+    for (int j = 0; j < 8; ++j) {
+        a[j] = __builtin_bit_cast(__bf16, A[i * 32 + 8 * q + j]);      // A[row i][k = 8 q + j]
+        b[j] = __builtin_bit_cast(__bf16, B[(8 * q + j) * 16 + i]);    // B[k = 8 q + j][column i]
+    }
+    v4f32 c;
+    for (int r = 0; r < 4; ++r) c[r] = C[(4 * q + r) * 16 + i];
+    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+    for (int r = 0; r < 4; ++r) D[(4 * q + r) * 16 + i] = c[r];
+}
+
 // ---- certified bf16 filter path (kmeans_filter.h): d <= 10 and centres + images fit the LDS -------------
 bool filter_enabled() {
     static const bool on = [] {
@@ -1037,6 +1056,28 @@ msm_status msm_kmeans_filter_scanned(msm_ctx* ctx, uint64_t* h_out, int reset) {
     MSM_HIP(ctx, hipStreamSynchronize(ctx->stream));
     MSM_HIP(ctx, hipMemcpy(h_out, ctx->km_stats, 8, hipMemcpyDeviceToHost));
     if (reset) MSM_HIP(ctx, hipMemset(ctx->km_stats, 0, 8));
+    return MSM_OK;
+}
+
+msm_status msm_mfma_bf16_probe(msm_ctx* ctx, const uint16_t* h_a, const uint16_t* h_b, const float* h_c, float* h_d,
+                               int n_tiles) {
+    if (!ctx) return MSM_ERR_INVALID;
+    MSM_REQUIRE(ctx, n_tiles >= 1 && h_a && h_b && h_c && h_d, "msm_mfma_bf16_probe: bad arguments");
+    const size_t na = (size_t)n_tiles * 512 * sizeof(uint16_t), nc = (size_t)n_tiles * 256 * sizeof(float);
+    msm_status rs = msm_reserve_scratch(ctx, 2 * na + 2 * nc);
+    if (rs != MSM_OK) return rs;
+    unsigned char* base = (unsigned char*)ctx->scratch;
+    uint16_t* d_a = (uint16_t*)base;
+    uint16_t* d_b = (uint16_t*)(base + na);
+    float* d_c = (float*)(base + 2 * na);
+    float* d_d = (float*)(base + 2 * na + nc);
+    MSM_HIP(ctx, hipMemcpyAsync(d_a, h_a, na, hipMemcpyHostToDevice, ctx->stream));
+    MSM_HIP(ctx, hipMemcpyAsync(d_b, h_b, na, hipMemcpyHostToDevice, ctx->stream));
+    MSM_HIP(ctx, hipMemcpyAsync(d_c, h_c, nc, hipMemcpyHostToDevice, ctx->stream));
+    hipLaunchKernelGGL(mfma_bf16_probe_kernel, dim3((unsigned)n_tiles), dim3(64), 0, ctx->stream, d_a, d_b, d_c, d_d);
+    MSM_CHECK_LAUNCH(ctx);
+    MSM_HIP(ctx, hipMemcpyAsync(h_d, d_d, nc, hipMemcpyDeviceToHost, ctx->stream));
+    MSM_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return MSM_OK;
 }
 

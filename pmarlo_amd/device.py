@@ -594,6 +594,20 @@ class Engine:
         check(lib.msm_kmeans_filter_scanned(self.handle, C.byref(out), int(reset)), self.handle)
         return int(out.value)
 
+    def mfma_bf16_probe(self, a_bits: np.ndarray, b_bits: np.ndarray, c: np.ndarray) -> np.ndarray:
+        """D = A B + C through one v_mfma_f32_16x16x32_bf16 per tile: a_bits [t, 16, 32], b_bits [t, 32, 16] uint16
+        (raw bf16 patterns), c [t, 16, 16] float32 (host arrays).  The hardware rule behind the k-means filter."""
+        a = np.ascontiguousarray(a_bits, np.uint16)
+        b = np.ascontiguousarray(b_bits, np.uint16)
+        cc = np.ascontiguousarray(c, np.float32)
+        t = a.shape[0]
+        if a.shape != (t, 16, 32) or b.shape != (t, 32, 16) or cc.shape != (t, 16, 16):
+            raise ValueError("mfma_bf16_probe: shapes must be [t,16,32], [t,32,16], [t,16,16]")
+        out = np.empty((t, 16, 16), np.float32)
+        check(lib.msm_mfma_bf16_probe(self.handle, a.ctypes.data, b.ctypes.data, cc.ctypes.data, out.ctypes.data, t),
+              self.handle)
+        return out
+
     def kmeans_update(self, sums: DeviceArray, counts: DeviceArray, centers: DeviceArray, state: DeviceArray,
                       clear: bool = True):
         k, d = centers.shape

@@ -7,12 +7,16 @@ What is exchanged, by plain summation over RCCL / xGMI:
   exchange                      payload                         when
   lagged moments + the          2F^2 + 2F + 1 + 3F f64          once (one buffer, one collective)
     standardisation sums
-  k-means fixed-point scale     1 f64 (MIN) + centres bcast     once
-  k-means member sums / counts  k*d + k int64 (exact)           per Lloyd iteration
+  k-means start                 k*d + 1 f64, ONE MIN: rank 0's  once
+                                centres (the other ranks offer
+                                1.4e306) and the coarsest
+                                fixed-point scale
+  k-means member sums / counts  k*d + k int64 (exact), reduced  per Lloyd iteration
+                                out of the persistent local sums
   transition counts             k^2 int64 (exact), or the       once (one collective for a whole
                                 L k^2 + L block of a lag scan     lag scan)
 
-i.e. 4 + kmeans_iters collectives per step with TICA, 3 + kmeans_iters without (`ShardedMSM.collectives_per_step`).
+i.e. 3 + kmeans_iters collectives per step with TICA, 2 + kmeans_iters without (`ShardedMSM.collectives_per_step`).
 Integer payloads make the result independent of the number of shards bit for bit; the fp64 moment sums are
 gathered and added in rank order (bit-identical on every rank, independent of the collective's schedule).
 
@@ -46,36 +50,61 @@ class Comm:
     rank = 0
 
     def allreduce_sum(self, name: str) -> None: ...
+    def allreduce_sum_from(self, name: str, src) -> None: ...     # buffer `name` = sum over ranks of the array `src`
     def allreduce_min(self, name: str) -> None: ...
     def allreduce_max(self, name: str) -> None: ...
     def broadcast(self, name: str, src: int = 0) -> None: ...
     def reciprocal(self, dst: str, src: str) -> None: ...
 
 
+def _id_file_default() -> Path:
+    """Node-local file that carries the RCCL id of THIS launch: keyed by the rendezvous port, the launcher's process id
+    and, under torchrun, the run id and restart count (a restarted group must not read the id of the group it replaces)."""
+    env = os.environ
+    key = "_".join([env.get("MASTER_PORT", "0"), str(os.getppid()), env.get("TORCHELASTIC_RUN_ID", "none"),
+                    env.get("TORCHELASTIC_RESTART_COUNT", "0")])
+    key = "".join(ch if ch.isalnum() or ch in "_-" else "-" for ch in key)
+    return Path(env.get("MSM_COMM_ID_DIR", "/tmp")) / f"msm_comm_{key}.id"
+
+
+def _resolve_id_path(world: int) -> Path:
+    path = os.environ.get("MSM_COMM_ID_FILE")
+    if path is not None:
+        return Path(path)
+    nnodes = int(os.environ.get("GROUP_WORLD_SIZE", os.environ.get("NNODES", "1")) or 1)
+    local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)) or world)
+    if nnodes > 1 or local_world < world:
+        raise RuntimeError("the RCCL id travels through a node-local file by default: set MSM_COMM_ID_FILE to a path "
+                           "every node can read for a multi-node launch")
+    return _id_file_default()
+
+
 def bootstrap_id(rank: int, world: int, path: str | os.PathLike | None = None, timeout: float = 300.0) -> bytes:
     """Carry rank 0's RCCL unique id to the other ranks of this launch through a file.
 
-    The default name is keyed by MASTER_PORT and the parent process id (the launcher that started every rank
-    of the node), so concurrent or earlier launches do not collide; MSM_COMM_ID_FILE overrides it."""
+    MSM_COMM_ID_FILE names the file (it must be visible to every rank: a shared file system when the job spans nodes);
+    without it the file is node-local (`_id_file_default`), so a multi-node launch is refused rather than left to time
+    out.  Rank 0 removes whatever an earlier launch left under the name before it draws the id, and the file is removed
+    again once the communicator stands (`NativeComm.from_env`)."""
     from ._lib import check, lib
 
-    if path is None:
-        path = os.environ.get("MSM_COMM_ID_FILE") or (
-            f"/tmp/msm_comm_{os.environ.get('MASTER_PORT', '0')}_{os.getppid()}.id")
-    path = Path(path)
+    path = Path(path) if path is not None else _resolve_id_path(world)
     if rank == 0:
         buf = (C.c_ubyte * 128)()
         check(lib.msm_comm_unique_id(buf, 128), None)
         tmp = path.with_suffix(f".tmp{os.getpid()}")
         tmp.write_bytes(bytes(buf))
-        os.replace(tmp, path)
+        os.replace(tmp, path)          # atomic: a reader sees the old file, no file, or all 128 new bytes
         return bytes(buf)
     t0 = time.monotonic()
+    started = time.time()
     while True:
         try:
-            data = path.read_bytes()
-            if len(data) == 128:
-                return data
+            # a file older than this process belongs to an earlier launch that used the same name
+            if path.stat().st_mtime >= started - float(os.environ.get("MSM_COMM_ID_MAX_AGE", "120")):
+                data = path.read_bytes()
+                if len(data) == 128:
+                    return data
         except FileNotFoundError:
             pass
         if time.monotonic() - t0 > timeout:
@@ -97,11 +126,49 @@ class NativeComm(Comm):
         check(lib.msm_comm_init(engine.handle, self.rank, self.world, idbuf, 128, C.byref(handle)), engine.handle)
         self.handle = handle
         self._id_file = id_file
+        # per-collective timing (bench.py): HIP events on the engine's stream around every call, keyed by buffer name
+        self.timing = False
+        self.events: dict[str, list] = {}
 
     @classmethod
     def from_env(cls, engine: Engine, bufs: dict[str, DeviceArray]) -> "NativeComm":
         rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
-        return cls(engine, bufs, rank, world, bootstrap_id(rank, world))
+        path = _resolve_id_path(world)
+        if rank == 0:
+            try:
+                os.unlink(path)      # nothing of an earlier launch may sit under this name
+            except OSError:
+                pass
+        self = cls(engine, bufs, rank, world, bootstrap_id(rank, world, path), id_file=path)
+        # the communicator stands on every rank once a collective has completed: the id file has done its work
+        if "timing" in bufs:
+            self.allreduce_max("timing")
+            engine.sync()
+            if rank == 0:
+                try:
+                    os.unlink(path)
+                except OSError:
+                    pass
+        return self
+
+    def comm_info(self) -> tuple[int, int]:
+        """(rank, world) as the communicator itself reports them."""
+        r, w = C.c_int32(0), C.c_int32(0)
+        self._check(self._lib.msm_comm_info(self.handle, C.byref(r), C.byref(w), None), self.eng.handle)
+        return int(r.value), int(w.value)
+
+    def _timed(self, name, call):
+        if not self.timing:
+            return call()
+        e0, e1 = self.eng.event(), self.eng.event()
+        e0.record()
+        call()
+        e1.record()
+        self.events.setdefault(name, []).append((e0, e1))
+
+    def exchange_ms(self) -> dict[str, float]:
+        """Device time between the events around the collectives of each named buffer, summed (call after a sync)."""
+        return {nm: float(sum(a.elapsed_ms(b) for a, b in evs)) for nm, evs in self.events.items()}
 
     def close(self) -> None:
         if getattr(self, "handle", None):
@@ -125,19 +192,27 @@ class NativeComm(Comm):
         fn = self._lib.msm_allreduce_i64 if a.dtype == np.int64 else self._lib.msm_allreduce_f64
         if a.dtype not in (np.dtype(np.int64), np.dtype(np.float64)):
             raise TypeError(f"exchange buffer {name!r} must be int64 or float64")
-        self._check(fn(self.handle, a.ptr, a.size), self.eng.handle)
+        self._timed(name, lambda: self._check(fn(self.handle, a.ptr, a.size), self.eng.handle))
+
+    def allreduce_sum_from(self, name, src):
+        a = self.b[name]
+        if a.dtype != np.dtype(np.int64) or src.dtype != a.dtype or src.size != a.size:
+            raise TypeError(f"exchange buffer {name!r}: the out-of-place sum takes int64 arrays of one size")
+        self._timed(name, lambda: self._check(self._lib.msm_allreduce_i64_from(self.handle, src.ptr, a.ptr, a.size),
+                                              self.eng.handle))
 
     def allreduce_min(self, name):
         a = self.b[name]
-        self._check(self._lib.msm_allreduce_min_f64(self.handle, a.ptr, a.size), self.eng.handle)
+        self._timed(name, lambda: self._check(self._lib.msm_allreduce_min_f64(self.handle, a.ptr, a.size), self.eng.handle))
 
     def allreduce_max(self, name):
         a = self.b[name]
-        self._check(self._lib.msm_allreduce_max_f64(self.handle, a.ptr, a.size), self.eng.handle)
+        self._timed(name, lambda: self._check(self._lib.msm_allreduce_max_f64(self.handle, a.ptr, a.size), self.eng.handle))
 
     def broadcast(self, name, src=0):
         a = self.b[name]
-        self._check(self._lib.msm_broadcast(self.handle, a.ptr, a.nbytes, int(src)), self.eng.handle)
+        self._timed(name, lambda: self._check(self._lib.msm_broadcast(self.handle, a.ptr, a.nbytes, int(src)),
+                                              self.eng.handle))
 
     def reciprocal(self, dst, src):
         self.eng.rcp(self.b[src], self.b[dst])
@@ -146,11 +221,13 @@ class NativeComm(Comm):
 class TorchComm(Comm):
     """torch.distributed collectives on named torch tensors (device or, for gloo tests, host)."""
 
-    def __init__(self, tensors: dict):
+    def __init__(self, tensors: dict, views: dict | None = None):
+        """`views`: the engine's arrays over the same memory as `tensors` (needed for `allreduce_sum_from`)."""
         import torch.distributed as dist
 
         self.dist = dist
         self.t = tensors
+        self.v = views
         self.world = dist.get_world_size()
         self.rank = dist.get_rank()
         self._gather: dict = {}
@@ -184,6 +261,15 @@ class TorchComm(Comm):
         for r in range(1, self.world):
             acc += buf[r]
         t.copy_(acc)
+
+    def allreduce_sum_from(self, name, src):
+        """t[name] = sum over ranks of the engine array `src`: torch.distributed reduces in place, so the engine copies
+        `src` into the exchange buffer first (same stream as the collective)."""
+        if self.v is None:
+            raise RuntimeError("TorchComm needs the engine's views of the exchange buffers for an out-of-place sum")
+        self.v[name].copy_from(src)
+        self.n_collectives += 1
+        self.dist.all_reduce(self.t[name], op=self.dist.ReduceOp.SUM)
 
     def allreduce_min(self, name):
         self.n_collectives += 1
@@ -232,7 +318,8 @@ def exchange_shapes(cfg: ShardConfig) -> dict[str, tuple[tuple[int, ...], str]]:
         # [lagged moments 2F^2 + 2F + 1 | standardisation sums 3F]: both are raw sums about the shared shift
         "moments": ((2 * F * F + 2 * F + 1 + 3 * F,), "float64"),
         "fit_state": ((8,), "float64"),
-        "centers": ((k, d), "float64"),
+        # [centres k d | fixed-point scale]: one MIN collective gives every rank rank 0's centres and the coarsest scale
+        "start": ((k * d + 1,), "float64"),
         "km_acc": ((k * d + k,), "int64"),
         "counts": ((L * k * k + L,), "int64"),   # the pair counts ride at the end: one collective
     }
@@ -240,10 +327,11 @@ def exchange_shapes(cfg: ShardConfig) -> dict[str, tuple[tuple[int, ...], str]]:
 
 def exchange_aliases(cfg: ShardConfig) -> dict[str, tuple[str, int, int]]:
     """name -> (parent buffer, first element, length) of the named parts of exchange buffers."""
-    F = cfg.n_features
+    F, d, k = cfg.n_features, cfg.cluster_dim, cfg.k
     L = 2 * F * F + 2 * F + 1
     return {"lagged": ("moments", 0, L), "mom_sums": ("moments", L, 3 * F),
-            "fit_scale": ("fit_state", 0, 1), "fit_inv_scale": ("fit_state", 1, 1)}
+            "fit_scale": ("fit_state", 0, 1), "fit_inv_scale": ("fit_state", 1, 1),
+            "centers": ("start", 0, k * d), "start_scale": ("start", k * d, 1)}
 
 
 class ShardedMSM:
@@ -269,6 +357,7 @@ class ShardedMSM:
         for name, (parent, first, length) in exchange_aliases(cfg).items():
             if name not in b:
                 b[name] = b[parent].view((length,), offset_elems=first)
+        b["centers"] = b["start"].view((k, d))          # the kernels take the centres as a [k, d] table
         # featurize front stage: xyz stays resident, the feature matrix is rebuilt by every step
         if cfg.n_atoms > 0:
             if cfg.pairs is None or len(cfg.pairs) != F:
@@ -319,7 +408,7 @@ class ShardedMSM:
 
     @property
     def collectives_per_step(self) -> int:
-        return (4 if self.cfg.tica_dim > 0 else 3) + self.cfg.kmeans_iters
+        return (3 if self.cfg.tica_dim > 0 else 2) + self.cfg.kmeans_iters
 
     def _stamp(self, name: str):
         if self.time_stages:
@@ -359,11 +448,15 @@ class ShardedMSM:
         eng.kmeans_fit_begin(self.Y, k, seed=cfg.seed, n_total=self.n_total, tol2=0.0, centers=b["centers"],
                              state=b["fit_state"], absmax_ready=cfg.tica_dim > 0)
         if multi:
-            # identical start on every rank: rank 0's centres; the coarsest fixed-point scale
-            # (state = {scale, inv_scale, ...}: MIN of scale, inv_scale follows as its reciprocal)
-            comm.broadcast("centers", 0)
-            comm.allreduce_min("fit_scale")
-            comm.reciprocal("fit_inv_scale", "fit_scale")   # 2^-e: exact, no second collective
+            # identical start on every rank in ONE collective: the MIN over [centres | scale] where every rank but 0
+            # offers 0x7F7F... = 1.4e306 for the centres (finite coordinates pass through bit for bit) and its own
+            # fixed-point scale (state = {scale, inv_scale, ...}; inv_scale follows as the reciprocal: 2^-e, exact)
+            if comm.rank != 0:
+                b["centers"].fill_bytes_(0x7F)
+            b["start_scale"].copy_from(b["fit_scale"])
+            comm.allreduce_min("start")
+            b["fit_scale"].copy_from(b["start_scale"])
+            comm.reciprocal("fit_inv_scale", "fit_scale")
         acc = self.km_local if self.km_local is not None else b["km_acc"]
         acc.zero_()
         acc_sums, acc_counts = acc.view((k * d,), np.int64), acc.view((k,), np.int64, offset_elems=k * d)
@@ -380,8 +473,7 @@ class ShardedMSM:
                 e1.record()
                 self.accum_events.append((e0, e1))
             if multi:
-                b["km_acc"].copy_from(self.km_local)
-                comm.allreduce_sum("km_acc")
+                comm.allreduce_sum_from("km_acc", self.km_local)     # out of place: no copy in front of the collective
             eng.kmeans_update(self.km_sums, self.km_counts, b["centers"], b["fit_state"], clear=False)
         eng.kmeans_assign(self.Y, b["centers"], labels=self.labels, image=self.km_image)
         self._stamp("kmeans")
@@ -424,3 +516,4 @@ def torch_exchange_buffers(engine: Engine, cfg: ShardConfig, device) -> tuple[di
         tensors[name] = tensors[parent][first:first + length]
         views[name] = views[parent].view((length,), offset_elems=first)
     return tensors, views
+

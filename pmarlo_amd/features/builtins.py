@@ -6,6 +6,8 @@ side effect of ``compute``), and ``astype(float)`` outputs with NaN -> 0 (:307,3
 
 from __future__ import annotations
 
+import logging
+
 import numpy as np
 
 from ..device import get_engine
@@ -167,6 +169,19 @@ class ContactsPairFeature(_PairKwFeature):
         return out.to_host().astype(float)
 
 
+def _zeros_after_failure(feature: str, exc: Exception, shape: tuple[int, int]) -> np.ndarray:
+    """The reference wraps the mdtraj call of ``sasa`` / ``hbonds_count`` / ``ssfrac`` in ``except Exception`` and
+    continues with a column of zeros (S/features/builtins.py:176-246); so does the engine, for failures of the
+    COMPUTATION (an element without a radius, a device-side limit such as more neighbours than the kernel's list
+    holds), and says so in the log.  A missing library or device is not such a failure: there is no CPU path to
+    fall back to, so that error travels on."""
+    if isinstance(exc, ImportError):
+        raise exc
+    logging.getLogger("pmarlo").warning("feature %r failed (%s: %s); the reference's fallback applies: zeros", feature,
+                                        type(exc).__name__, exc)
+    return np.zeros(shape, dtype=float)
+
+
 class SASAFeature:
     """``sasa``: total Shrake-Rupley solvent accessible surface per frame, the sum of the per-residue areas
     (S/features/builtins.py:171-188).  Like the reference, any failure of the computation (an element without a
@@ -180,13 +195,14 @@ class SASAFeature:
 
     def compute(self, traj, **kwargs) -> np.ndarray:
         self.labels = ["sasa"]
+        get_engine()   # no device, no library: that error is not one the zero column stands for
         try:
             from .structure import shrake_rupley
 
             sasa = shrake_rupley(traj, mode="residue")  # (n_frames, n_residues)
             return np.sum(sasa, axis=1, keepdims=True).astype(float)
-        except (ValueError, KeyError, IndexError):
-            return np.zeros((traj.n_frames, 1), dtype=float)
+        except Exception as exc:
+            return _zeros_after_failure("sasa", exc, (traj.n_frames, 1))
 
     def is_periodic(self) -> np.ndarray:
         return self._periodic
@@ -204,13 +220,14 @@ class HBondsCountFeature:
 
     def compute(self, traj, **kwargs) -> np.ndarray:
         self.labels = ["hbonds_count"]
+        get_engine()   # no device, no library: that error is not one the zero column stands for
         try:
             from .structure import baker_hubbard
 
             hbonds = baker_hubbard(traj, periodic=True)
             return np.full((traj.n_frames, 1), float(len(hbonds)), dtype=float)
-        except (ValueError, KeyError, IndexError):
-            return np.zeros((traj.n_frames, 1), dtype=float)
+        except Exception as exc:
+            return _zeros_after_failure("hbonds_count", exc, (traj.n_frames, 1))
 
     def is_periodic(self) -> np.ndarray:
         return self._periodic
@@ -228,6 +245,7 @@ class SecondaryStructureFractionFeature:
 
     def compute(self, traj, **kwargs) -> np.ndarray:
         self.labels = ["ssfrac:helix", "ssfrac:sheet", "ssfrac:coil"]
+        get_engine()   # no device, no library: that error is not one the zero column stands for
         try:
             from .structure import compute_dssp
 
@@ -238,8 +256,8 @@ class SecondaryStructureFractionFeature:
             sheet = np.isin(dssp, ["E", "B"]).sum(axis=1) / n
             coil = np.maximum(0.0, 1.0 - helix - sheet)
             return np.stack([helix, sheet, coil], axis=1).astype(float)
-        except (ValueError, KeyError, IndexError):
-            return np.zeros((traj.n_frames, 3), dtype=float)
+        except Exception as exc:
+            return _zeros_after_failure("ssfrac", exc, (traj.n_frames, 3))
 
     def is_periodic(self) -> np.ndarray:
         return self._periodic

@@ -11,9 +11,12 @@ dependency of this engine; this module restates the published grammar for the fo
                ``index < 100``, ``resSeq >= 5``, ``name == CA``, ``element != H``
   logic        and / or / not (also && || !), parentheses
 
-Residue classes follow mdtraj: protein = the standard amino-acid residue names (plus common protonation variants and
-caps ACE / NME / NH2 are NOT protein), water = HOH / WAT / H2O / TIP3 / SOL ..., backbone = protein atoms named
-N, CA, C, O, sidechain = protein atoms not named N, CA, C, O, HA, H.  Unknown words raise ValueError, as mdtraj does."""
+Residue classes follow mdtraj's published tables (mdtraj/core/residue_names.py, restated here because mdtraj is not
+installed: `protein` is its _PROTEIN_RESIDUES -- the amino acids, their protonation / force-field variants (ASH, GLH,
+HID / HIE / HIP, HSD / HSE / HSP, LYSH, CYX ...), the N- and C-terminal AMBER names (NALA, CALA ...) and the CAPS
+ACE / NME / NAC / NH2 / NHE, so the reference's standard test system ACE-ALA-NME is protein throughout; `water` is its
+_WATER_RESIDUES), backbone = protein atoms named N, CA, C, O, sidechain = protein atoms not named N, CA, C, O, HA, H.
+Unknown words raise ValueError, as mdtraj does."""
 
 from __future__ import annotations
 
@@ -23,9 +26,19 @@ import numpy as np
 
 __all__ = ["select", "PROTEIN_RESIDUES", "WATER_RESIDUES"]
 
-PROTEIN_RESIDUES = frozenset("""ALA ARG ASN ASP CYS GLN GLU GLY HIS ILE LEU LYS MET PHE PRO SER THR TRP TYR VAL
-ASH CYM CYX GLH HID HIE HIP HSD HSE HSP LYN ASX GLX PYL SEC UNK""".split())
-WATER_RESIDUES = frozenset("HOH WAT H2O TIP TIP2 TIP3 TIP4 SOL W".split())
+_AMINO = "ALA ARG ASN ASP CYS GLN GLU GLY HIS ILE LEU LYS MET PHE PRO SER THR TRP TYR VAL".split()
+PROTEIN_RESIDUES = frozenset(
+    _AMINO
+    # caps and unusual residues
+    + "ACE NME NAC NH2 NHE CT3 AIB DALA HYP ORN PYRR MELEU MEVAL LSN QLN".split()
+    # protonation states and force-field spellings
+    + """ARGN ASN1 ASP1 ASPH ASH CYS1 CYS2 CYSH CYM CYX GLUH GLH HID HIE HIP HIS1 HISA HISB HISH HISD HISE HISP
+         HSD HSE HSP LYSH LYN""".split()
+    # AMBER names of the chain ends
+    + ["N" + r for r in _AMINO + ["HID", "HIE", "HIP", "CYX"]] + ["C" + r for r in _AMINO + ["HID", "HIE", "HIP", "CYX"]]
+    # kept from earlier rounds of this module (ambiguous / rare codes PDB files carry)
+    + "ASX GLX PYL SEC UNK".split())
+WATER_RESIDUES = frozenset("H2O HHO OHH HOH OH2 SOL WAT TIP TIP2 TIP3 TIP4 W".split())
 _BACKBONE = frozenset(("N", "CA", "C", "O"))
 _NOT_SIDECHAIN = frozenset(("N", "CA", "C", "O", "HA", "H"))
 

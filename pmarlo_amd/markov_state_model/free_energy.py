@@ -126,6 +126,10 @@ class FESResult:
                  cv1_name=None, cv2_name=None, temperature=None) -> None:
         if F is None and free_energy is None:
             raise TypeError("FESResult requires either 'F' or 'free_energy' to be provided")
+        if F is not None and free_energy is not None:
+            import warnings
+
+            warnings.warn("Both 'F' and 'free_energy' were provided; using 'F'", RuntimeWarning, stacklevel=2)
         self.F = np.asarray(F if F is not None else free_energy, dtype=np.float64)
         self.xedges = np.asarray(xedges, dtype=np.float64)
         self.yedges = np.asarray(yedges, dtype=np.float64)
@@ -153,6 +157,61 @@ class FESResult:
     @property
     def free_energy(self) -> np.ndarray:
         return self.F
+
+    def __getitem__(self, key: str):
+        """Mapping-style access of older callers (``fes["F"]``): deprecated, as in the reference (free_energy.py:133-157)."""
+        import warnings
+
+        warnings.warn("Dictionary-style access to FESResult is deprecated; use attributes instead.", DeprecationWarning,
+                      stacklevel=2)
+        if key in ("F", "xedges", "yedges", "levels_kJmol"):
+            return getattr(self, key)
+        raise KeyError(key)
+
+    # ---- the reference's wire format (free_energy.py:159-251): arrays as nested lists, or {"shape", "dtype"} stubs ----
+    def to_dict(self, metadata_only: bool = False) -> dict:
+        def plain(v):
+            if isinstance(v, np.ndarray):
+                return {"shape": list(v.shape), "dtype": str(v.dtype)} if metadata_only else v.tolist()
+            return v
+
+        out = {"version": self.version, "free_energy": plain(self.F), "xedges": plain(self.xedges), "yedges": plain(self.yedges)}
+        for key in ("levels_kJmol", "counts"):
+            if getattr(self, key) is not None:
+                out[key] = plain(getattr(self, key))
+        if self.temperature is not None:
+            out["temperature"] = float(self.temperature)
+        for key in ("cv1_name", "cv2_name"):
+            if getattr(self, key) is not None:
+                out[key] = getattr(self, key)
+        # what lives in attributes is not repeated under "metadata"
+        rest = {k: plain(v) for k, v in self.metadata.items() if k not in ("counts", "temperature", "cv1_name", "cv2_name")}
+        if rest:
+            out["metadata"] = rest
+        return out
+
+    @classmethod
+    def from_dict(cls, data: dict) -> "FESResult":
+        raw = dict(data)
+        version = raw.pop("version", cls.version)
+        if version not in ("1.0", "2.0"):
+            raise ValueError(f"Version mismatch: {version} != {cls.version}")
+
+        def back(v):
+            if isinstance(v, dict) and "shape" in v and "dtype" in v:      # a metadata_only stub: zeros of that shape
+                return np.zeros(tuple(int(x) for x in v["shape"]), dtype=np.dtype(v.get("dtype", "float64")))
+            return np.asarray(v) if isinstance(v, list) else v
+
+        extra = raw.pop("metadata", None) or {}
+        temperature = raw.pop("temperature", None)
+        opt = {key: raw.pop(key, None) for key in ("levels_kJmol", "counts")}
+        return cls(F=back(raw.pop("free_energy")), xedges=back(raw.pop("xedges")), yedges=back(raw.pop("yedges")),
+                   levels_kJmol=None if opt["levels_kJmol"] is None else back(opt["levels_kJmol"]),
+                   counts=None if opt["counts"] is None else back(opt["counts"]),
+                   metadata={k: back(v) for k, v in extra.items()},
+                   cv1_name=raw.pop("cv1_name", None) or extra.get("cv1_name"),
+                   cv2_name=raw.pop("cv2_name", None) or extra.get("cv2_name"),
+                   temperature=temperature if temperature is not None else extra.get("temperature"))
 
 
 def _reference_crop_is_live() -> bool:

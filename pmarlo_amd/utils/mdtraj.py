@@ -1,72 +1,78 @@
-"""Mirror of pmarlo.utils.mdtraj (S/utils/mdtraj.py): topology loading and atom-selection resolution, on the
-engine's own PDB topology and selection parser instead of mdtraj's (same names, arguments and error behaviour:
-``on_error`` = raise / warn / ignore, empty selections count as failures, sequences of ints or digit strings)."""
+"""Topology loading and atom-selection resolution for the engine's own PDB topology.
+
+Stands where the reference has ``pmarlo.utils.mdtraj`` (S/utils/mdtraj.py:21-92) and keeps its two public names
+and their contract, since callers are written against it:
+
+* ``load_mdtraj_topology(path)`` -> a topology object with ``select(expression)``;
+* ``resolve_atom_selection(topo, selection, logger=, on_error=)`` -> list of int atom indices, or ``None``
+  when no selection was asked for or the selection failed under a non-raising policy.
+
+A selection is a failure when the expression does not parse, when an entry of an index list is not an integer
+(ints, numpy ints and digit strings are), or when it names no atom at all.  ``on_error`` decides what a failure
+does: ``"raise"`` (default) raises ``ValueError``, ``"warn"`` logs one warning on ``logger`` and yields ``None``,
+``"ignore"`` yields ``None`` silently.  mdtraj itself is not needed: expressions go to
+``pmarlo_amd.io.selection`` (the mdtraj selection grammar on ``pmarlo_amd.io.pdb.Topology``)."""
 
 from __future__ import annotations
 
 import logging
 import os
+from dataclasses import dataclass
 from pathlib import Path
-from typing import Callable, Literal, Sequence
+from typing import Literal, Sequence
 
 from ..io.pdb import Topology, load_pdb
 
 __all__ = ["load_mdtraj_topology", "resolve_atom_selection"]
 
+_POLICIES = ("raise", "warn", "ignore")
+
 
 def load_mdtraj_topology(topology: str | os.PathLike[str] | Path) -> Topology:
-    """Load a topology from a PDB file (the reference: ``mdtraj.load_topology``, :21-24)."""
-    return load_pdb(str(Path(topology))).topology
+    """Topology of a PDB file."""
+    return load_pdb(os.fspath(topology)).topology
 
 
-def _validate_on_error(on_error: str) -> None:
-    if on_error not in {"raise", "warn", "ignore"}:
-        raise ValueError("on_error must be 'raise', 'warn', or 'ignore'")
+@dataclass(frozen=True)
+class _FailurePolicy:
+    mode: str
+    logger: logging.Logger | None
+
+    def failed(self, reason: str, cause: Exception | None = None) -> None:
+        """A selection could not be resolved: raise, warn or stay silent; returning means 'no selection'."""
+        if self.mode == "raise":
+            if cause is not None:
+                raise cause
+            raise ValueError(reason)
+        if self.mode == "warn" and self.logger is not None:
+            self.logger.warning("atom selection failed: %s", cause if cause is not None else reason)
 
 
-def _resolve_selection_from_string(topo: Topology, expression: str,
-                                   handle_failure: Callable[[Exception | None], None]) -> Sequence[int] | None:
-    try:
-        selection = topo.select(expression)
-    except (ValueError, TypeError) as exc:
-        handle_failure(exc)
-        return None
-    if selection.size == 0:
-        handle_failure(None)
-        return None
-    return [int(i) for i in selection]
-
-
-def _resolve_selection_from_sequence(selection: Sequence[int | str],
-                                     handle_failure: Callable[[Exception | None], None]) -> Sequence[int] | None:
-    try:
-        indices = [int(item, 10) if isinstance(item, str) else int(item) for item in selection]
-    except (TypeError, ValueError) as exc:
-        handle_failure(exc)
-        return None
-    if not indices:
-        handle_failure(None)
-        return None
-    return indices
+def _indices_of(topo: Topology, selection) -> list[int]:
+    """Atom indices named by an expression or listed one by one; raises ValueError / TypeError for what is neither."""
+    if isinstance(selection, str):
+        return [int(i) for i in topo.select(selection)]
+    out = []
+    for entry in selection:
+        out.append(int(entry, 10) if isinstance(entry, str) else int(entry))
+    return out
 
 
 def resolve_atom_selection(topo: Topology, atom_selection: str | Sequence[int] | None, *,
                            logger: logging.Logger | None = None,
                            on_error: Literal["raise", "warn", "ignore"] = "raise") -> Sequence[int] | None:
-    """Resolve an atom selection against ``topo`` (S/utils/mdtraj.py:67-92)."""
+    """Atom indices for ``atom_selection`` (expression, or sequence of indices) on ``topo``; see the module text."""
     if atom_selection is None:
         return None
-    _validate_on_error(on_error)
-
-    def _handle_failure(exc: Exception | None) -> None:
-        if on_error == "raise":
-            if exc is None:
-                raise ValueError("atom selection produced no atoms")
-            raise exc
-        if on_error == "warn" and logger is not None:
-            msg = "atom selection failed"
-            logger.warning(msg if exc is None else f"{msg}: {exc}")
-
-    if isinstance(atom_selection, str):
-        return _resolve_selection_from_string(topo, atom_selection, _handle_failure)
-    return _resolve_selection_from_sequence(atom_selection, _handle_failure)
+    if on_error not in _POLICIES:
+        raise ValueError("on_error must be 'raise', 'warn', or 'ignore'")
+    policy = _FailurePolicy(on_error, logger)
+    try:
+        indices = _indices_of(topo, atom_selection)
+    except (TypeError, ValueError) as exc:
+        policy.failed("atom selection could not be read", exc)
+        return None
+    if not indices:
+        policy.failed("atom selection produced no atoms")
+        return None
+    return indices

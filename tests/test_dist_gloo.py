@@ -2,8 +2,9 @@
 N > 1 -- with a host stand-in for the engine (tests/_host_engine.py: numpy + the CPU oracle behind the Engine
 interface) and TorchComm over gloo.  What can only go wrong with more than one rank is what is checked:
 the shared shift broadcast, the single moments collective over the aliased buffers, the rank-ordered fp64 sum,
-the centres broadcast, the MIN of the fixed-point scale and its reciprocal, the int64 member-sum reduction ordered
-against kmeans_update(clear=True), the count reduction (single lag and the batched lag scan)."""
+the one MIN collective that carries rank 0's centres and the coarsest fixed-point scale (and its reciprocal), the
+out-of-place int64 member-sum reduction ordered against kmeans_update, the count reduction (single lag and the
+batched lag scan)."""
 
 from __future__ import annotations
 
@@ -49,16 +50,17 @@ def _worker(rank: int, world: int, port: int, out_dir: str, mode: str) -> None:
     for name, (parent, first, length) in exchange_aliases(cfg).items():
         tensors[name] = tensors[parent][first:first + length]
         views[name] = views[parent].view((length,), offset_elems=first)
-    comm = TorchComm(tensors)
+    comm = TorchComm(tensors, views)
     eng = HostEngine()
     X = _gen.correlated_series(N, F, seed=1000 + rank)
     msm = ShardedMSM(eng, cfg, eng.to_device(X), comm=comm, shared=views)
-    assert msm.collectives_per_step == (4 if mode == "tica" else 3) + ITERS
+    assert msm.collectives_per_step == (3 if mode == "tica" else 2) + ITERS
     before = comm.n_collectives
     msm.step()
     assert comm.n_collectives - before == msm.collectives_per_step
     msm.step()          # a second step must start from clean accumulators
     out = {nm: a.copy() for nm, a in arrays.items()}
+    out["centers"] = arrays["start"][:K * cfg.cluster_dim].reshape(K, cfg.cluster_dim).copy()
     out.update(Y=np.asarray(msm.Y.a, np.float64).copy(), labels=msm.labels.a.copy(), T=msm.T.a.copy())
     if mode == "tica":
         out.update(eig=msm.eig.a.copy(), mean=msm.mean.a.copy(), scale=msm.scale.a.copy())
@@ -168,7 +170,8 @@ def test_exchange_payload_sizes_match_survey():
     nbytes = {k: int(np.prod(s)) * 8 for k, (s, _) in sh.items()}
     assert nbytes["moments"] == (2 * 64 * 64 + 2 * 64 + 1 + 3 * 64) * 8   # ~68 KB: lagged moments + the sums
     assert nbytes["km_acc"] == (500 * 10 + 500) * 8             # 44 KB per Lloyd iteration
+    assert nbytes["start"] == (500 * 10 + 1) * 8                # centres + scale: one MIN collective
     assert nbytes["counts"] == (500 * 500 + 1) * 8              # 2 MB (+ the pair count)
     sh4 = exchange_shapes(ShardConfig(n_frames=100_000, n_features=45, tica_dim=0, k=200, lag=1, lags=tuple(range(1, 51))))
     assert int(np.prod(sh4["counts"][0])) * 8 == (50 * 200 * 200 + 50) * 8   # one 16 MB collective
-    assert sh4["centers"][0] == (200, 45)
+    assert sh4["start"][0] == (200 * 45 + 1,)

@@ -49,6 +49,37 @@ def test_every_filter_width(engine, d, dtype):
     _check(engine, X, centers, X.mean(0, dtype=np.float64), X.std(0, dtype=np.float64) + 0.25)
 
 
+@pytest.mark.parametrize("d", [1, 2, 4])
+@pytest.mark.parametrize("k", [1025, 1100, 1400])
+def test_more_than_64_tiles(engine, d, k):
+    """One matrix instruction per tile (d <= 4) leaves LDS room for more than 64 tiles of centres: assign (with and
+    without a prebuilt image), the whole fit and the delta-mode passes, against the C restatement."""
+    rng = np.random.default_rng(1000 * d + k)
+    n = 40_009
+    X = np.cumsum(rng.normal(size=(n, d)), axis=0) * 0.05 + rng.normal(size=(n, d))
+    centers = X[rng.choice(n, size=k, replace=False)] + 1e-5 * rng.normal(size=(k, d))
+    _check(engine, X, centers)
+    want_c, _, _ = cport.kmeans_fit(X, k, seed=5, max_iter=4, tol2=0.0)
+    x = engine.to_device(X)
+    got_c, _ = engine.kmeans_fit(x, k, seed=5, max_iter=4, tol2=0.0)
+    np.testing.assert_array_equal(got_c.to_host(), want_c)
+    # pass by pass: full sums against delta sums on one image
+    img = engine.kmeans_pack(x)
+    c2, st2 = engine.kmeans_fit_begin(x, k, seed=5, n_total=n, tol2=0.0)
+    c3, st3 = engine.kmeans_fit_begin(x, k, seed=5, n_total=n, tol2=0.0)
+    sums2, counts2 = engine.zeros((k * d,), np.int64), engine.zeros((k,), np.int64)
+    sums3, counts3 = engine.zeros((k * d,), np.int64), engine.zeros((k,), np.int64)
+    prev = engine.empty((n,), np.int32)
+    prev.fill_bytes_(0xFF)
+    for _ in range(4):
+        engine.kmeans_accumulate(x, c2, st2, sums2, counts2, image=img)
+        engine.kmeans_update(sums2, counts2, c2, st2, clear=True)
+        engine.kmeans_accumulate(x, c3, st3, sums3, counts3, image=img, prev_labels=prev)
+        engine.kmeans_update(sums3, counts3, c3, st3, clear=False)
+    np.testing.assert_array_equal(c2.to_host(), want_c)
+    np.testing.assert_array_equal(c3.to_host(), want_c)
+
+
 def test_near_ties_and_duplicates(engine):
     """Frames on bisector planes, centres that differ in the last bits, duplicated centres: every frame the
     filter cannot certify must come out of the exhaustive scan with the pinned tie rule (lowest index)."""

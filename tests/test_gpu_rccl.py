@@ -38,7 +38,7 @@ def _launch(nproc: int, extra_env: dict, args: list[str]) -> dict:
 def test_sharded_step_through_rccl_c_abi_single_rank():
     out = _launch(1, {"BENCH_FORCE_EXCHANGE": "1"}, ["--frames", "200000"])
     assert out["n_gpus"] == 1 and out["config"]["exchange"] == "rccl (C ABI)"
-    assert out["config"]["collectives_per_step"] == 14        # 4 + kmeans_iters
+    assert out["config"]["collectives_per_step"] == 13        # 3 + kmeans_iters (moments, start, counts)
     par = out["parity"]
     assert "error" not in par, par
     assert par["counts_bit_exact"] and par["labels_bit_exact_given_centres"]
@@ -48,7 +48,7 @@ def test_sharded_step_through_rccl_c_abi_single_rank():
 
 def test_sharded_step_two_ranks_one_gpu_gloo():
     out = _launch(2, {"BENCH_COMM": "torch", "BENCH_BACKEND": "gloo", "BENCH_SAME_GPU": "1"}, ["--frames", "150000"])
-    assert out["n_gpus"] == 2 and out["config"]["collectives_per_step"] == 14
+    assert out["n_gpus"] == 2 and out["config"]["collectives_per_step"] == 13
     par = out["parity"]
     assert "error" not in par, par
     assert par["labels_bit_exact_given_centres"]
@@ -59,7 +59,7 @@ def test_sharded_step_two_ranks_one_gpu_gloo():
 def test_lag_scan_config_through_rccl_c_abi_single_rank():
     """BASELINE config 4 shape: featurize on the device every step, no TICA, 50 lags in one pass and ONE collective."""
     out = _launch(1, {"BENCH_FORCE_EXCHANGE": "1"}, ["--config", "c4", "--frames", "60000"])
-    assert out["config"]["collectives_per_step"] == 13        # 3 + kmeans_iters
+    assert out["config"]["collectives_per_step"] == 12        # 2 + kmeans_iters
     par = out["parity"]
     assert "error" not in par, par
     assert par["counts_bit_exact"] and par["labels_bit_exact_given_centres"]

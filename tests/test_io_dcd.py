@@ -102,3 +102,27 @@ def test_topology_attachment_and_errors(tmp_path):
         DCDFile(bad)
     assert isinstance(load_dcd(p, top=Trajectory(xyz, Topology(["a", "b", "c"], ["X"] * 3, np.zeros(3, dtype=int)))),
                       Trajectory)
+
+
+def test_capped_dipeptide_is_protein_throughout(tmp_path):
+    """ACE-ALA-NME, the reference's standard test system: mdtraj's residue tables count the caps as protein, so
+    `protein`, `backbone` and `sidechain` cover them (S/utils/mdtraj.py:31-44 hands these strings to mdtraj)."""
+    from pmarlo_amd.io.pdb import load_pdb
+
+    atoms = [("HH31", "ACE", 1), ("CH3", "ACE", 1), ("HH32", "ACE", 1), ("HH33", "ACE", 1), ("C", "ACE", 1), ("O", "ACE", 1),
+             ("N", "ALA", 2), ("H", "ALA", 2), ("CA", "ALA", 2), ("HA", "ALA", 2), ("CB", "ALA", 2), ("HB1", "ALA", 2),
+             ("HB2", "ALA", 2), ("HB3", "ALA", 2), ("C", "ALA", 2), ("O", "ALA", 2), ("N", "NME", 3), ("H", "NME", 3),
+             ("CH3", "NME", 3), ("HH31", "NME", 3), ("HH32", "NME", 3), ("HH33", "NME", 3), ("O", "HOH", 4), ("H1", "HOH", 4)]
+    lines = []
+    for i, (nm, res, seq) in enumerate(atoms):
+        el = "H" if nm[0] == "H" else nm[0]
+        lines.append(f"ATOM  {i + 1:5d} {nm:<4s} {res:>3s} A{seq:4d}    {0.1 * i:8.3f}{0.0:8.3f}{0.0:8.3f}  1.00  0.00          {el:>2s}")
+    p = tmp_path / "ala2.pdb"
+    p.write_text("\n".join(lines) + "\nEND\n")
+    top = load_pdb(p).topology
+    assert list(top.select("protein")) == list(range(22))
+    assert list(top.select("water")) == [22, 23]
+    names = [a[0] for a in atoms]
+    assert list(top.select("backbone")) == [i for i in range(22) if names[i] in ("N", "CA", "C", "O")]
+    assert list(top.select("sidechain")) == [i for i in range(22) if names[i] not in ("N", "CA", "C", "O", "HA", "H")]
+    assert list(top.select("protein and name CA")) == [8]
