@@ -377,6 +377,15 @@ msm_status msm_kmeans_fit(msm_ctx* ctx, const void* d_x, msm_dtype dtype, int64_
                           const double* d_mean, const double* d_std, int k, uint64_t seed,
                           int init_centers, int max_iter, double tol2, double* d_centers,
                           double* d_state);
+/* k-means++ seeding (deeptime KMeans init_strategy = 'kmeans++', S/markov_state_model/clustering.py:322-361;
+ * sklearn KMeans init = 'k-means++', S/analysis/discretize.py:458-469): after msm_kmeans_fit_begin (which leaves
+ * max |z| in d_state[2]) this replaces the k centres by frames drawn with probability proportional to the squared
+ * distance to the nearest centre already drawn.  Integer weights and splitmix64 draws (csrc/kmeanspp.hip): the
+ * frames drawn are a function of the data and the seed alone, and oracle/npport.kmeans_plusplus repeats them bit
+ * for bit.  d_picked (int64 [k], may be NULL) receives the frame numbers. */
+msm_status msm_kmeans_init_plusplus(msm_ctx* ctx, const void* d_x, msm_dtype dtype, int64_t n, int d, int64_t ld,
+                                    const double* d_mean, const double* d_std, int k, uint64_t seed, double n_total,
+                                    double* d_centers, const double* d_state, int64_t* d_picked);
 msm_status msm_kmeans_fit_begin(msm_ctx* ctx, const void* d_x, msm_dtype dtype, int64_t n, int d,
                                 int64_t ld, const double* d_mean, const double* d_std, int k,
                                 uint64_t seed, int init_centers, double n_total, double tol2,

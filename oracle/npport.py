@@ -1457,3 +1457,57 @@ def _roundf(x):
     """C roundf: half away from zero, float32."""
     x = np.float32(x)
     return np.float32(np.sign(x) * np.floor(np.abs(x) + np.float32(0.5)))
+
+
+# ---------------------------------------------------------------------------------------------------------
+# k-means++ seeding as the engine defines it (pmarlo_amd/csrc/kmeanspp.hip): integer weights, splitmix64 draws
+# ---------------------------------------------------------------------------------------------------------
+_M64 = (1 << 64) - 1
+
+
+def _kpp_hash(seed: int, j: int) -> int:
+    h = ((seed ^ 0x6B2B2B6B6D65616E) + 0x9E3779B97F4A7C15 * (j + 1)) & _M64
+    h = ((h ^ (h >> 30)) * 0xBF58476D1CE4E5B9) & _M64
+    h = ((h ^ (h >> 27)) * 0x94D049BB133111EB) & _M64
+    return h ^ (h >> 31)
+
+
+def kmeans_plusplus(Y, k: int, seed: int, n_total=None, mean=None, std=None):
+    """Indices and coordinates of the k frames the device's k-means++ seeding draws (test infrastructure).
+
+    D^2 with a separate multiply and add per feature in ascending order, integer weights rint(D^2 2^e) with 2^e from
+    max |z| (frexp), draw j = floor(h_j W / 2^64) against the cumulative integer weights."""
+    Z = np.asarray(Y, np.float64)
+    if mean is not None:
+        Z = (Z - np.asarray(mean, np.float64)) / np.asarray(std, np.float64)
+    n, d = Z.shape
+    n_total = float(n if n_total is None else n_total)
+    absmax = float(np.nanmax(np.abs(Z))) if Z.size else 0.0
+    if not absmax > 0.0:
+        absmax = 1.0
+    v = (n_total * 4.0 * float(d)) * absmax * absmax
+    _, ex = np.frexp(v)
+    e = int(np.clip(61 - int(ex), -900, 60))
+    scale = float(np.ldexp(1.0, e))
+    seed &= _M64
+    picked = [(_kpp_hash(seed, 0) * n) >> 64]
+    mind = None
+    for j in range(1, k):
+        c = Z[picked[-1]]
+        a = np.zeros(n)
+        for f in range(d):
+            diff = Z[:, f] - c[f]
+            a = a + diff * diff
+        mind = a if mind is None else np.where(a < mind, a, mind)
+        mind = np.where(np.isnan(mind), 0.0, mind)
+        w = np.rint(mind * scale).astype(np.int64)
+        cum = np.cumsum(w)
+        W = int(cum[-1])
+        h = _kpp_hash(seed, j)
+        if W <= 0:
+            picked.append((h * n) >> 64)
+        else:
+            r = (h * W) >> 64
+            picked.append(int(np.searchsorted(cum, r, side="right")))
+    idx = np.asarray(picked, np.int64)
+    return idx, Z[idx].copy()

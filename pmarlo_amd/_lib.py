@@ -101,6 +101,7 @@ _PROTOTYPES: dict[str, tuple] = {
     "msm_kmeans_accumulate_delta": (_i32, [_vp, _vp, _i32, _i64, _i32, _i64, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp,
                                            _vp]),
     "msm_kmeans_filter_scanned": (_i32, [_vp, C.POINTER(C.c_uint64), _i32]),
+    "msm_kmeans_init_plusplus": (_i32, [_vp, _vp, _i32, _i64, _i32, _i64, _vp, _vp, _i32, C.c_uint64, _f64, _vp, _vp, _vp]),
     "msm_mfma_bf16_probe": (_i32, [_vp, _vp, _vp, _vp, _vp, _i32]),
     "msm_run_lengths": (_i32, [_vp, _vp, _i64, _i32, _vp, _vp, _vp, _i64, _vp]),
     "msm_sum_f64": (_i32, [_vp, _vp, _i64, _vp]),

@@ -226,11 +226,19 @@ def _coerce_weights(weights: Any, n_frames: int, split_name: str) -> np.ndarray 
 
 class KMeansDiscretizer:
     """_KMeansDiscretizer: whitening (mean, std ddof=1, std_safe) + k-means; ``fit`` runs the
-    engine's Lloyd, or adopts ``centers`` (whitened space) when given (parity mode)."""
+    engine's Lloyd, or adopts ``centers`` (whitened space) when given (parity mode).
+
+    The reference fits sklearn ``KMeans(n_init=10)`` (k-means++ starts) below 5e6 elements and ``MiniBatchKMeans``
+    above (S/analysis/discretize.py:402-403, 458-469).  Here: below that size ``n_init`` restarts of full-batch Lloyd
+    from k-means++ seeds on the device, lowest inertia kept; above it one full-batch Lloyd from the seeded stratified
+    draw (where the reference trades quality for time, and so does the seeding: see cluster_microstates)."""
+
+    _KMEANS_MAX_ELEMENTS = 5_000_000
 
     def __init__(self, n_states: int, *, random_state: int | None = None, apply_whitening: bool = True,
-                 centers: np.ndarray | None = None, max_iter: int = 100) -> None:
+                 centers: np.ndarray | None = None, max_iter: int = 100, n_init: int = 3) -> None:
         self.n_states = int(n_states)
+        self.n_init = max(1, int(n_init))
         self.random_state = random_state
         self.apply_whitening = bool(apply_whitening)
         self.max_iter = int(max_iter)
@@ -271,8 +279,22 @@ class KMeansDiscretizer:
             if n < self.n_states:
                 raise ValueError(f"n_samples={n} should be >= n_clusters={self.n_states}.")
             pipe = MSMPipeline(eng)
-            _, self._centers_d, _ = pipe.cluster(xd, self.n_states, seed=int(self.random_state or 0),
-                                                 max_iter=self.max_iter, tol=1e-4, whiten=whiten)
+            seed = int(self.random_state or 0)
+            if n * d >= self._KMEANS_MAX_ELEMENTS:
+                _, self._centers_d, _ = pipe.cluster(xd, self.n_states, seed=seed, max_iter=self.max_iter, tol=1e-4,
+                                                     whiten=whiten)
+            else:
+                best = None
+                md = eng.empty((n,), np.float64)
+                mean_d, std_d = whiten if whiten is not None else (None, None)
+                for r in range(self.n_init):
+                    c0 = eng.kmeans_init_plusplus(xd, self.n_states, seed=seed + 7919 * r, mean=mean_d, std=std_d)
+                    _, cen, _ = pipe.cluster(xd, self.n_states, seed=seed, max_iter=self.max_iter, tol=1e-4, whiten=whiten,
+                                             centers=c0, mindist=md)
+                    inertia = float(eng.sum_f64(md).to_host()[0])
+                    if best is None or inertia < best[0]:
+                        best = (inertia, cen)
+                self._centers_d = best[1]
 
     def transform(self, X: np.ndarray, feature_schema: Mapping[str, Any] | None = None, *,
                   split_name: str | None = None) -> np.ndarray:

@@ -531,6 +531,57 @@ class Engine:
                                  state.ptr), self.handle)
         return centers, state
 
+    def kmeans_init_plusplus(self, x: DeviceArray, k: int, *, seed: int = 0, mean: DeviceArray | None = None,
+                             std: DeviceArray | None = None, n_total: int | None = None,
+                             centers: DeviceArray | None = None, return_picked: bool = False):
+        """k-means++ seeding on the device (csrc/kmeanspp.hip): centres [k, d] f64 = frames drawn with probability
+        proportional to the squared distance to the nearest centre already drawn (deterministic in the data and seed)."""
+        n, d = x.shape
+        n_total = n if n_total is None else int(n_total)
+        centers, state = self.kmeans_fit_begin(x, k, seed=seed, n_total=n_total, tol2=0.0, mean=mean, std=std,
+                                               centers=centers, init_centers=False)
+        picked = self.empty((k,), np.int64) if return_picked else None
+        check(lib.msm_kmeans_init_plusplus(self.handle, x.ptr, _dtype_code(x.dtype), n, d, d,
+                                           mean.ptr if mean is not None else None, std.ptr if std is not None else None,
+                                           int(k), int(seed) & (2**64 - 1), float(n_total), centers.ptr, state.ptr,
+                                           picked.ptr if picked is not None else None), self.handle)
+        return (centers, picked) if return_picked else centers
+
+    def kmeans_fit_minibatch(self, x: DeviceArray, k: int, *, seed: int = 0, batch_size: int = 100, max_iter: int = 5,
+                             init: str = "kmeans++", centers: DeviceArray | None = None,
+                             max_batches: int = 4096) -> tuple[DeviceArray, DeviceArray]:
+        """Mini-batch k-means (Sculley; what sklearn's MiniBatchKMeans and deeptime's do with their batches): the
+        frames are dealt into `nb` interleaved batches (batch b = frames b, b + nb, ...: a batch of a time series should
+        not be one stretch of it), every batch is assigned to the current centres and ADDED to the running member sums,
+        and the centres are the running means -- `max_iter` sweeps over all batches.  nb = ceil(n / batch_size), at
+        most `max_batches` (two launches per batch).  Same kernels as the full-batch fit (msm_kmeans_accumulate /
+        msm_kmeans_update through their row stride), so the sums are exact fixed point and the result is
+        deterministic."""
+        n, d = x.shape
+        if batch_size < 1 or max_iter < 0:
+            raise ValueError("batch_size must be >= 1 and max_iter >= 0")
+        given = centers is not None
+        # the running sums see every frame once per sweep: the fixed-point scale is sized for n * max_iter terms
+        n_terms = n * max(1, int(max_iter))
+        centers, state = self.kmeans_fit_begin(x, k, seed=seed, n_total=n_terms, tol2=0.0, centers=centers,
+                                               init_centers=not given and init != "kmeans++")
+        if not given and init == "kmeans++":
+            check(lib.msm_kmeans_init_plusplus(self.handle, x.ptr, _dtype_code(x.dtype), n, d, d, None, None, int(k),
+                                               int(seed) & (2**64 - 1), float(n_terms), centers.ptr, state.ptr, None),
+                  self.handle)
+        nb = max(1, min(int(max_batches), -(-n // int(batch_size))))
+        sums, counts = self.zeros((k * d,), np.int64), self.zeros((k,), np.int64)
+        item = x.dtype.itemsize
+        for _ in range(int(max_iter)):
+            for b in range(nb):
+                rows = (n - b + nb - 1) // nb
+                if rows <= 0:
+                    continue
+                check(lib.msm_kmeans_accumulate(self.handle, x.ptr + b * d * item, _dtype_code(x.dtype), rows, d, nb * d,
+                                                centers.ptr, k, None, None, state.ptr, sums.ptr, counts.ptr), self.handle)
+                check(lib.msm_kmeans_update(self.handle, sums.ptr, counts.ptr, k, d, centers.ptr, state.ptr, 0), self.handle)
+        return centers, state
+
     def kmeans_fit_begin(self, x: DeviceArray, k: int, *, seed: int, n_total: int, tol2: float,
                          mean: DeviceArray | None = None, std: DeviceArray | None = None,
                          centers: DeviceArray | None = None, init_centers: bool = True,

@@ -39,10 +39,19 @@ class ClusteringResult:
         return (self.n_states,)
 
 
-def _fit_once(pipe, yd, k, seed, max_iter, tol, init):
+def _fit_once(pipe, yd, k, seed, max_iter, tol, init, init_strategy="kmeans++", minibatch=None):
+    """One fit from one start: `init` (given centres), else k-means++ seeding or the seeded stratified draw; `minibatch`
+    = batch size of the mini-batch estimator (None: full-batch Lloyd)."""
     eng = pipe.eng
     md = eng.empty((yd.shape[0],), np.float64)
     centers0 = eng.to_device(np.ascontiguousarray(init, np.float64)) if init is not None else None
+    if centers0 is None and init_strategy == "kmeans++" and minibatch is None:
+        centers0 = eng.kmeans_init_plusplus(yd, k, seed=seed)
+    if minibatch is not None:
+        centers0, _ = eng.kmeans_fit_minibatch(yd, k, seed=seed, batch_size=minibatch, max_iter=max_iter,
+                                               init=init_strategy, centers=centers0)
+        labels, centers, _ = pipe.cluster(yd, k, centers=centers0, mindist=md, fit=False)
+        return labels, centers, float(eng.sum_f64(md).to_host()[0])
     labels, centers, _ = pipe.cluster(yd, k, seed=seed, max_iter=max_iter, tol=tol, centers=centers0, mindist=md)
     inertia = float(eng.sum_f64(md).to_host()[0])
     return labels, centers, inertia
@@ -99,7 +108,8 @@ def _auto_select_n_states(Y, random_state, *, sample_size, override_n_states, kw
         best = None
         for r in range(max(3, int(kwargs.get("n_init", 1)))):
             labels, _, inertia = _fit_once(pipe, yd, k, seed + 7919 * r, int(kwargs.get("max_iter", 100)),
-                                           float(kwargs.get("tolerance", 1e-5)), None)
+                                           float(kwargs.get("tolerance", 1e-5)), None,
+                                           _init_strategy(kwargs, int(Ys.size)))
             if best is None or inertia < best[1]:
                 best = (labels, inertia)
         lab = best[0].to_host()
@@ -121,6 +131,18 @@ def _validate_clustering_kwargs(method: str, kwargs: dict) -> None:
     metric = kwargs.get("metric", "euclidean")
     if metric not in ("euclidean", None):
         raise NotImplementedError(f"metric={metric!r}: the device k-means is Euclidean (deeptime's default)")
+
+
+def _init_strategy(kwargs: dict, n_elements: int = 0, threshold: int = 5_000_000) -> str:
+    """deeptime's KMeans takes init_strategy 'kmeans++' (its default, and what the reference gets) or 'uniform'
+    (k frames at random: here the seeded stratified draw along the time axis).  Without the keyword: k-means++ for
+    inputs the reference clusters with full-batch KMeans, the stratified draw above ``minibatch_threshold`` where the
+    reference itself gives up quality for time (k-means++ costs two launches and a pass over the data per centre:
+    15 ms at 1 M x 10, k = 500, three times the whole fit)."""
+    strategy = kwargs.get("init_strategy", "kmeans++" if n_elements <= threshold else "uniform")
+    if strategy not in ("kmeans++", "uniform"):
+        raise ValueError(f"init_strategy must be 'kmeans++' or 'uniform', got {strategy!r}")
+    return strategy
 
 
 def _resolve_seed(random_state: int | None, kwargs: dict) -> int:
@@ -166,10 +188,13 @@ def cluster_microstates(
     """k-means microstates on the GPU; same signature, keyword set, errors and result as the reference
     (S/markov_state_model/clustering.py:395-665).
 
-    ``method`` only decides which keywords are legal: on this engine every size runs full-batch Lloyd (the
-    reference switches to mini-batch above ``minibatch_threshold`` to bound CPU time), so ``batch_size``,
-    ``n_jobs``, ``progress`` and ``init_strategy`` are accepted and have no effect (the start is the engine's
-    seeded stratified draw, or ``initial_centers``).  Labels are densified and centres recomputed as member
+    ``method="kmeans"`` is full-batch Lloyd, ``method="minibatchkmeans"`` the mini-batch estimator
+    (``batch_size``, default 100 as deeptime's; ``max_iter`` sweeps over the batches), ``method="auto"`` always
+    full-batch: the reference switches to mini-batch above ``minibatch_threshold`` to bound CPU time, which is not
+    a concern here (a full-batch pass over 1 M x 10 takes 0.1 ms and ends at a lower inertia).  The start is
+    ``init_strategy``: "kmeans++" (deeptime's default: D^2 seeding on the device) or "uniform" (seeded stratified
+    draw), or ``initial_centers``; ``n_jobs`` and ``progress`` have no meaning on the device and are ignored.
+    Labels are densified and centres recomputed as member
     means as the reference does after its estimator returns (:364-392) -- on the device: member sums come out of
     one more accumulate pass in exact fixed point, the relabelling is a device gather."""
     Y = np.asarray(Y)
@@ -197,7 +222,8 @@ def cluster_microstates(
     _validate_clustering_kwargs(method, kwargs)
     if method not in ("auto", "minibatchkmeans", "kmeans"):
         raise ValueError(f"Unsupported clustering method: {method}")
-    for ignored in ("n_jobs", "progress", "init_strategy", "batch_size"):
+    strategy = _init_strategy(kwargs, int(Y.shape[0] * Y.shape[1]), int(minibatch_threshold))
+    for ignored in ("n_jobs", "progress"):
         if ignored in kwargs:
             logger.debug("cluster_microstates: %s=%r has no effect on the device estimator", ignored, kwargs[ignored])
     rationale = None
@@ -212,8 +238,15 @@ def cluster_microstates(
     k = int(n_states)
     if k <= 0:
         raise ValueError(f"Number of microstates must be a positive integer; received {k}.")
-    chosen = ("minibatchkmeans" if int(Y.shape[0] * Y.shape[1]) > minibatch_threshold else "kmeans") \
-        if method == "auto" else method
+    # "auto": the reference would pick mini-batch above the threshold; the device estimator stays full-batch (docstring)
+    would = "minibatchkmeans" if int(Y.shape[0] * Y.shape[1]) > minibatch_threshold else "kmeans"
+    chosen = "kmeans" if method == "auto" else method
+    if method == "auto" and would == "minibatchkmeans":
+        if "batch_size" in kwargs:
+            chosen = "minibatchkmeans"      # the caller asked for batches and the reference would use them here
+        else:
+            logger.info("cluster_microstates: %d x %d exceeds minibatch_threshold; the device estimator runs full-batch "
+                        "Lloyd all the same", Y.shape[0], Y.shape[1])
     if "batch_size" in kwargs and chosen != "minibatchkmeans":
         raise ValueError(f"batch_size was provided but the selected clustering method is '{chosen}'. "
                          "Specify method='minibatchkmeans' to use mini-batch parameters.")
@@ -222,7 +255,7 @@ def cluster_microstates(
     eng = get_engine()
     pipe = MSMPipeline(eng)
     yd = eng.to_device(np.ascontiguousarray(Y))
-    max_iter = int(kwargs.get("max_iter", 100))
+    max_iter = int(kwargs.get("max_iter", 5 if chosen == "minibatchkmeans" else 100))
     tol = float(kwargs.get("tolerance", 1e-5))
     init = kwargs.get("initial_centers", kwargs.get("init_centers"))
     if init is not None:
@@ -232,7 +265,8 @@ def cluster_microstates(
     best = None
     for it, seed in enumerate(_restart_seeds(random_state, n_init)):  # restarts keep the lowest inertia (:584-629)
         s = _resolve_seed(seed, kwargs)
-        labels, centers, inertia = _fit_once(pipe, yd, k, s, max_iter, tol, init)
+        labels, centers, inertia = _fit_once(pipe, yd, k, s, max_iter, tol, init, strategy,
+                                             int(kwargs.get("batch_size", 100)) if chosen == "minibatchkmeans" else None)
         if best is None or inertia < best[2]:
             best = (labels, centers, inertia, seed, it)
     if n_init > 1:

@@ -181,13 +181,17 @@ def test_cluster_microstates_takes_the_reference_keywords(engine):
     Y, true_centers = _gen.gaussian_clusters(6, 500, 4, seed=5)
     Y = Y[np.random.default_rng(1).permutation(Y.shape[0])]
     base = cluster_microstates(Y, n_states=6, random_state=3, max_iter=50, tolerance=1e-6)
-    # accepted and without effect on the device estimator
+    # n_jobs / progress: accepted and without effect on the device estimator; init_strategy / metric: the defaults
     same = cluster_microstates(Y, method="kmeans", n_states=6, random_state=3, max_iter=50, tolerance=1e-6, n_jobs=4,
                                progress=None, init_strategy="kmeans++", metric="euclidean")
     np.testing.assert_array_equal(base.labels, same.labels)
-    mb = cluster_microstates(Y, method="minibatchkmeans", n_states=6, random_state=3, max_iter=50, tolerance=1e-6,
+    # the mini-batch estimator is a different estimator (tests/test_gpu_kmeanspp.py); on six separated blobs it finds
+    # the same partition
+    mb = cluster_microstates(Y, method="minibatchkmeans", n_states=6, random_state=3, max_iter=5, tolerance=1e-6,
                              batch_size=256)
-    np.testing.assert_array_equal(base.labels, mb.labels)
+    assert mb.n_states == 6
+    remap = {int(a): int(b) for a, b in zip(mb.labels, base.labels)}
+    np.testing.assert_array_equal(np.array([remap[int(a)] for a in mb.labels]), base.labels)
     # initial_centers (the reference's spelling) starts the fit there: the true centres recover the blobs
     seeded = cluster_microstates(Y, n_states=6, initial_centers=true_centers, max_iter=20)
     assert seeded.n_states == 6

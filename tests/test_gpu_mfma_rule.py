@@ -1,6 +1,6 @@
 """The hardware rule the k-means filter's certificate rests on (pmarlo_amd/csrc/kmeans_filter.h, step 1):
 v_mfma_f32_16x16x32_bf16 sums its 32 products and C with an error of at most 33 x 2^-24 of the largest term,
-whatever the order of the slots.  The bound was measured on one MI355X (tools/probe/bf16_filter_probe.hip); this
+in any order of the slots.  The bound was measured on one MI355X (tools/probe/bf16_filter_probe.hip); this
 test repeats the measurement through the C ABI on every box the suite runs on, so that a part with a narrower
 internal accumulator fails here and not in a label."""
 
@@ -60,18 +60,22 @@ def test_accumulation_error_bound(engine):
     assert worst <= 33.0, f"accumulation error {worst:.2f} x 2^-24 of the largest term exceeds the filter's bound"
 
 
-def test_slot_order_is_irrelevant(engine):
-    """The filter orders its 64 slots for the layout of the frame images; the sum must not depend on the order."""
+def test_any_slot_order_stays_inside_the_bound(engine):
+    """The filter orders its 64 slots for the layout of the frame images (kmeans_filter.h, filter_slot).  The sum is
+    NOT bit-identical under a permutation of the slots (the instruction adds groups of products, each group rounded
+    on its own), so what the certificate may use is the bound, for every order."""
     rng = np.random.default_rng(7)
     t = 8
     a = _bf16_bits(rng.normal(size=(t, 16, 32)) * np.exp2(rng.uniform(-10, 10, size=(t, 16, 32))))
     b = _bf16_bits(rng.normal(size=(t, 32, 16)) * np.exp2(rng.uniform(-10, 10, size=(t, 32, 16))))
     c = rng.normal(size=(t, 16, 16)).astype(np.float32)
-    ref = engine.mfma_bf16_probe(a, b, c)
-    for _ in range(4):
-        perm = rng.permutation(32)
-        got = engine.mfma_bf16_probe(a[:, :, perm], b[:, perm, :], c)
-        np.testing.assert_array_equal(got, ref)
+    want, big = _exact(a, b, c)
+    worst = 0.0
+    for trial in range(5):
+        perm = np.arange(32) if trial == 0 else rng.permutation(32)
+        got = engine.mfma_bf16_probe(a[:, :, perm], b[:, perm, :], c).astype(np.float64)
+        worst = max(worst, float((np.abs(got - want) / (big * U)).max()))
+    assert worst <= 33.0, f"a slot order gives {worst:.2f} x 2^-24 of the largest term"
 
 
 def test_filter_shaped_operands(engine):
