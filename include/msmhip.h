@@ -212,6 +212,11 @@ msm_status msm_column_moments_partial(msm_ctx* ctx, const void* d_x, msm_dtype d
                                       double* d_shift_out);
 msm_status msm_moments_finalize(msm_ctx* ctx, const double* d_sums, const double* d_shift, int F,
                                 int ddof, double* d_mean, double* d_std, double* d_count);
+/* The remaining column statistics of validate_features (S/analysis/validation.py:89-172): d_min / d_max [F] over the
+ * finite entries of every column (NaN for a column without any), d_counts int64 [2] = {non-finite entries, rows that
+ * are finite throughout}.  With msm_column_moments this replaces four host passes over the matrix. */
+msm_status msm_column_minmax(msm_ctx* ctx, const void* d_x, msm_dtype dtype, int64_t n, int F, int64_t ld,
+                             double* d_min, double* d_max, int64_t* d_counts);
 msm_status msm_column_moments(msm_ctx* ctx, const void* d_x, msm_dtype dtype, int64_t n, int F,
                               int64_t ld, int ddof, double* d_mean, double* d_std, double* d_count);
 

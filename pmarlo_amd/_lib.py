@@ -67,6 +67,7 @@ _PROTOTYPES: dict[str, tuple] = {
     "msm_column_moments_partial": (_i32, [_vp, _vp, _i32, _i64, _i32, _i64, _vp, _vp, _vp]),
     "msm_moments_finalize": (_i32, [_vp, _vp, _vp, _i32, _i32, _vp, _vp, _vp]),
     "msm_column_moments": (_i32, [_vp, _vp, _i32, _i64, _i32, _i64, _i32, _vp, _vp, _vp]),
+    "msm_column_minmax": (_i32, [_vp, _vp, _i32, _i64, _i32, _i64, _vp, _vp, _vp]),
     "msm_standardise_params": (_i32, [_vp, _vp, _vp, _i32, _f64, _i32, _vp, _vp, _vp]),
     "msm_lagged_moments": (_i32, [_vp, _vp, _i32, _i64, _i32, _i64, _vp, _vp, _i32, _i32, _vp, _i32, _vp]),
     "msm_tica_solve": (_i32, [_vp, _vp, _vp, _i32, _f64, _i32, _vp, _vp, _vp, _vp]),

@@ -251,7 +251,8 @@ class KMeansDiscretizer:
         self._std_d = None
         self._eng = get_engine()
 
-    def fit(self, X: np.ndarray, feature_schema: Mapping[str, Any] | None = None) -> None:
+    def fit(self, X: np.ndarray, feature_schema: Mapping[str, Any] | None = None, *, device_array=None) -> None:
+        """``device_array``: X already on the device (discretize_dataset uploads every split once)."""
         eng = self._eng
         n, d = X.shape
         schema = dict(feature_schema or {})
@@ -263,7 +264,8 @@ class KMeansDiscretizer:
         schema["names"] = [str(v) for v in names] if names else [f"feature_{i}" for i in range(d)]
         schema["n_features"] = d
         self.feature_schema = schema
-        xd = eng.to_device(_device_ready(X))      # float32 / float64 go up as they are: the kernels read both
+        # float32 / float64 go up as they are: the kernels read both
+        xd = device_array if device_array is not None else eng.to_device(_device_ready(X))
         whiten = None
         if self.apply_whitening:
             mean, std, _ = eng.column_moments(xd, ddof=1)
@@ -297,14 +299,16 @@ class KMeansDiscretizer:
                 self._centers_d = best[1]
 
     def transform(self, X: np.ndarray, feature_schema: Mapping[str, Any] | None = None, *,
-                  split_name: str | None = None) -> np.ndarray:
+                  split_name: str | None = None, device_array=None, return_device: bool = False):
         if self._centers_d is None:
             raise RuntimeError("Discretizer has not been fitted")
         if feature_schema is not None and self.feature_schema is not None:
             _validate_feature_schema(self.feature_schema, feature_schema, split_name=split_name or "split")
         eng = self._eng
-        labels = eng.kmeans_assign(eng.to_device(_device_ready(X)), self._centers_d, mean=self._mean_d, std=self._std_d)
-        return labels.to_host().astype(np.int32, copy=False)
+        xd = device_array if device_array is not None else eng.to_device(_device_ready(X))
+        labels = eng.kmeans_assign(xd, self._centers_d, mean=self._mean_d, std=self._std_d)
+        host = labels.to_host().astype(np.int32, copy=False)
+        return (host, labels) if return_device else host
 
     @property
     def centers(self) -> np.ndarray | None:
@@ -392,10 +396,10 @@ class GridDiscretizer:
         return {}
 
 
-def _device_counts(labels: np.ndarray, n_states: int, lag: int, weights, segments):
+def _device_counts(labels: np.ndarray, n_states: int, lag: int, weights, segments, labels_device=None):
     eng = get_engine()
     pipe = MSMPipeline(eng)
-    ld = eng.to_device(np.ascontiguousarray(labels, np.int32))
+    ld = labels_device if labels_device is not None else eng.to_device(np.ascontiguousarray(labels, np.int32))
     wd = eng.to_device(weights) if weights is not None else None
     counts, pairs = pipe.count(ld, n_states, lag, segments=segments, weights=wd)
     visits = eng.state_counts(ld, n_states).to_host()
@@ -418,13 +422,24 @@ def discretize_dataset(dataset: DatasetLike, *, cluster_mode: str = "kmeans", n_
     train_key = "train" if "train" in splits else next(iter(splits))
     train_data = _coerce_array(splits[train_key])
     feature_schema = _extract_feature_schema(splits[train_key], train_data.shape[1])
-    stats_by_split: Dict[str, Dict[str, Any]] = {train_key: validate_features(train_data, feature_schema["names"])}
-    if cluster_mode == "grid":
+    # every split goes to the device ONCE: validation, fit, assignment and counting share the copy
+    kmeans = cluster_mode != "grid"
+    on_device: Dict[str, Any] = {}
+
+    def device_copy(name: str, X: np.ndarray):
+        if name not in on_device:
+            on_device[name] = get_engine().to_device(_device_ready(X))
+        return on_device[name]
+
+    stats_by_split: Dict[str, Dict[str, Any]] = {
+        train_key: validate_features(train_data, feature_schema["names"], device_array=device_copy(train_key, train_data))}
+    if not kmeans:
         disc = GridDiscretizer(target_states=n_microstates)
+        disc.fit(train_data, feature_schema)
     else:
         disc = KMeansDiscretizer(n_microstates, random_state=random_state, apply_whitening=apply_whitening,
                                  centers=centers)
-    disc.fit(train_data, feature_schema)
+        disc.fit(train_data, feature_schema, device_array=on_device[train_key])
     feature_schema = disc.feature_schema or feature_schema
     stats_by_split[train_key]["feature_names"] = list(feature_schema["names"])
     stats_by_split[train_key]["n_features"] = int(feature_schema["n_features"])
@@ -432,15 +447,16 @@ def discretize_dataset(dataset: DatasetLike, *, cluster_mode: str = "kmeans", n_
     seg_len: Dict[str, List[int]] = {}
     seg_str: Dict[str, List[int]] = {}
     assignments: Dict[str, np.ndarray] = {}
+    labels_on_device: Dict[str, Any] = {}
     masks: Dict[str, np.ndarray] = {}
     max_state = -1
     for name, split in splits.items():
-        X = _coerce_array(split)
+        X = train_data if name == train_key else _coerce_array(split)
         schema = _extract_feature_schema(split, X.shape[1])
         _validate_feature_schema(feature_schema, schema, split_name=name)
         st = stats_by_split.get(name)
         if st is None:
-            st = validate_features(X, schema["names"])
+            st = validate_features(X, schema["names"], device_array=device_copy(name, X))
             stats_by_split[name] = st
         st["feature_names"] = list(schema["names"])
         st["n_features"] = int(schema["n_features"])
@@ -451,7 +467,12 @@ def discretize_dataset(dataset: DatasetLike, *, cluster_mode: str = "kmeans", n_
         st["segment_lengths"] = list(lengths)
         st["expected_pairs"] = expected_pairs(lengths, lag_time, strides if strides else 1)
         st["segment_strides"] = list(strides)
-        labels = disc.transform(X, feature_schema=schema, split_name=name)
+        if kmeans:
+            labels, labels_on_device[name] = disc.transform(X, feature_schema=schema, split_name=name,
+                                                            device_array=device_copy(name, X), return_device=True)
+            on_device.pop(name, None)      # the coordinates of this split are not needed again
+        else:
+            labels = disc.transform(X, feature_schema=schema, split_name=name)
         valid = labels >= 0
         if not valid.any():
             raise ValueError(f"No valid assignments found for split '{name}'")
@@ -469,7 +490,8 @@ def discretize_dataset(dataset: DatasetLike, *, cluster_mode: str = "kmeans", n_
     train_strides = seg_str.get(train_key) or []
     train_segments = _lengths_to_segments(train_lengths, train_labels.size)
 
-    counts_d, counted, visits, _ = _device_counts(train_labels, n_states, lag_time, weights, train_segments)
+    counts_d, counted, visits, _ = _device_counts(train_labels, n_states, lag_time, weights, train_segments,
+                                                  labels_device=labels_on_device.get(train_key))
     counts = counts_d.to_host().astype(np.float64)
     counts_before = counts.copy()
     counted_before = counted

@@ -1,6 +1,5 @@
 """validate_features: mirror of pmarlo.analysis.validation (S/analysis/validation.py:89-172).
-Column statistics come from the device moments kernel (+ a min/max pass on the host copy that
-the caller already holds)."""
+Column statistics come from the device (msm_column_moments, msm_column_minmax)."""
 
 from __future__ import annotations
 
@@ -32,23 +31,35 @@ class ValidationError(RuntimeError):
         super().__init__(f"{message} [code={self.code}] stats={summary}")
 
 
-def validate_features(X, feature_names: Sequence[str] | None) -> Dict[str, Any]:
-    array = np.asarray(X, dtype=np.float64)
+def validate_features(X, feature_names: Sequence[str] | None, *, device_array=None) -> Dict[str, Any]:
+    """Statistics and checks of a CV matrix.  The passes over the matrix run on the device (column moments; minima,
+    maxima, non-finite entries and fully finite rows in one more pass): ``device_array`` is the matrix already on the
+    device (discretize_dataset uploads every split once and shares it with the discretizer).  Only a matrix WITH
+    non-finite entries -- the error path -- is walked on the host, column by column, for the per-column statistics of
+    the finite subsets the error message carries."""
+    array = np.asarray(X)
+    if array.dtype not in (np.float32, np.float64):
+        array = array.astype(np.float64)
     if array.ndim != 2:
         raise ValueError(f"Expected 2D feature matrix, got shape {array.shape}")
     n_rows, n_features = array.shape
     names: List[str] = ([f"feature_{i}" for i in range(n_features)] if feature_names is None
                         else [str(v) for v in feature_names][:n_features])
     names += [f"feature_{i}" for i in range(len(names), n_features)]
-    finite = np.isfinite(array)
-    finite_rows = int(finite.all(axis=1).sum())
-    non_finite = int(finite.size - np.count_nonzero(finite))
-    if non_finite == 0 and n_rows > 0:
+    if n_rows > 0 and n_features > 0:
         eng = get_engine()
-        mean, std, _ = eng.column_moments(eng.to_device(np.ascontiguousarray(array)), ddof=0)
+        xd = device_array if device_array is not None else eng.to_device(np.ascontiguousarray(array))
+        mn, mx, cnt = eng.column_minmax(xd)
+        non_finite, finite_rows = (int(v) for v in cnt.to_host())
+    else:
+        non_finite, finite_rows = 0, int(n_rows)
+    if non_finite == 0 and n_rows > 0 and n_features > 0:
+        mean, std, _ = eng.column_moments(xd, ddof=0)
         means, stds = mean.to_host().tolist(), std.to_host().tolist()
-        mins, maxs = array.min(axis=0).tolist(), array.max(axis=0).tolist()
+        mins, maxs = mn.to_host().tolist(), mx.to_host().tolist()
     else:  # degenerate input: per-column finite subsets (error path)
+        array = array.astype(np.float64, copy=False)
+        finite = np.isfinite(array)
         means, stds, mins, maxs = [], [], [], []
         for j in range(n_features):
             col = array[:, j][finite[:, j]]

@@ -420,6 +420,72 @@ msm_status moments_partial_impl(msm_ctx* ctx, const T* x, int64_t n, int F, int6
 
 }  // namespace
 
+// column minima / maxima over the FINITE entries, the number of non-finite entries and of rows that are finite
+// throughout: what validate_features reports besides mean and std (S/analysis/validation.py:89-172).  One thread per
+// row; minima / maxima through the order-preserving 64-bit image of the doubles (LDS per workgroup, then global).
+namespace {
+__device__ __forceinline__ unsigned long long ordered_bits(double v) {
+    const unsigned long long b = (unsigned long long)__double_as_longlong(v);
+    return b ^ ((b >> 63) ? ~0ull : 0x8000000000000000ull);
+}
+template <typename T>
+__global__ __launch_bounds__(256) void column_minmax_kernel(const T* __restrict__ x, int64_t n, int F, int64_t ld,
+                                                           unsigned long long* __restrict__ gmin,
+                                                           unsigned long long* __restrict__ gmax,
+                                                           unsigned long long* __restrict__ counters) {
+    extern __shared__ unsigned long long smm[];   // [F] minima, [F] maxima
+    unsigned long long* lmin = smm;
+    unsigned long long* lmax = smm + F;
+    for (int f = threadIdx.x; f < F; f += 256) {
+        lmin[f] = ~0ull;
+        lmax[f] = 0ull;
+    }
+    __syncthreads();
+    unsigned long long bad_entries = 0, good_rows = 0;
+    for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < n; t += (int64_t)gridDim.x * 256) {
+        const T* row = x + t * ld;
+        bool all_ok = true;
+        for (int f = 0; f < F; ++f) {
+            const double v = (double)row[f];
+            if (fabs(v) <= 1.7976931348623157e308) {     // finite
+                const unsigned long long key = ordered_bits(v);
+                if (key < lmin[f]) atomicMin(&lmin[f], key);
+                if (key > lmax[f]) atomicMax(&lmax[f], key);
+            } else {
+                all_ok = false;
+                ++bad_entries;
+            }
+        }
+        good_rows += all_ok ? 1 : 0;
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        bad_entries += __shfl_down(bad_entries, off, 64);
+        good_rows += __shfl_down(good_rows, off, 64);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        if (bad_entries) atomicAdd(&counters[0], bad_entries);
+        if (good_rows) atomicAdd(&counters[1], good_rows);
+    }
+    __syncthreads();
+    for (int f = threadIdx.x; f < F; f += 256) {
+        if (lmin[f] != ~0ull) atomicMin(&gmin[f], lmin[f]);
+        if (lmax[f] != 0ull) atomicMax(&gmax[f], lmax[f]);
+    }
+}
+__global__ void column_minmax_finish_kernel(const unsigned long long* __restrict__ gmin, const unsigned long long* __restrict__ gmax,
+                                            int F, double* __restrict__ out_min, double* __restrict__ out_max) {
+    const int f = blockIdx.x * blockDim.x + threadIdx.x;
+    if (f >= F) return;
+    auto back = [](unsigned long long k) {
+        const unsigned long long b = k ^ ((k >> 63) ? 0x8000000000000000ull : ~0ull);
+        return __longlong_as_double((long long)b);
+    };
+    const double nan = __longlong_as_double(0x7FF8000000000000ll);
+    out_min[f] = gmin[f] == ~0ull ? nan : back(gmin[f]);
+    out_max[f] = gmax[f] == 0ull ? nan : back(gmax[f]);
+}
+}  // namespace
+
 extern "C" {
 
 msm_status msm_column_moments_partial(msm_ctx* ctx, const void* d_x, msm_dtype dtype, int64_t n, int F,
@@ -451,6 +517,35 @@ msm_status msm_standardise_params(msm_ctx* ctx, const double* d_sums, const doub
     MSM_REQUIRE(ctx, d_sums && d_shift && d_mean && d_scale && d_inv_scale, "msm_standardise_params: NULL pointer");
     hipLaunchKernelGGL(standardise_params_kernel, dim3(msm_ceil_div(F, 256)), dim3(256), 0, ctx->stream, d_sums, d_shift,
                        F, n_rows, with_std, d_mean, d_scale, d_inv_scale);
+    MSM_CHECK_LAUNCH(ctx);
+    return MSM_OK;
+}
+
+msm_status msm_column_minmax(msm_ctx* ctx, const void* d_x, msm_dtype dtype, int64_t n, int F, int64_t ld, double* d_min,
+                             double* d_max, int64_t* d_counts) {
+    if (!ctx) return MSM_ERR_INVALID;
+    MSM_REQUIRE(ctx, n >= 0 && F >= 1 && ld >= F, "msm_column_minmax: bad shape");
+    MSM_REQUIRE(ctx, dtype == MSM_F32 || dtype == MSM_F64, "msm_column_minmax: bad dtype");
+    MSM_REQUIRE(ctx, d_min && d_max && d_counts && (d_x || n == 0), "msm_column_minmax: NULL pointer");
+    msm_status rs = msm_reserve_scratch(ctx, (size_t)2 * F * sizeof(unsigned long long));
+    if (rs != MSM_OK) return rs;
+    unsigned long long* gmin = (unsigned long long*)ctx->scratch;
+    unsigned long long* gmax = gmin + F;
+    MSM_HIP(ctx, hipMemsetAsync(gmin, 0xFF, (size_t)F * sizeof(unsigned long long), ctx->stream));
+    MSM_HIP(ctx, hipMemsetAsync(gmax, 0, (size_t)F * sizeof(unsigned long long), ctx->stream));
+    MSM_HIP(ctx, hipMemsetAsync(d_counts, 0, 2 * sizeof(int64_t), ctx->stream));
+    if (n > 0) {
+        const int grid = (int)std::min<int64_t>((n + 255) / 256, (int64_t)ctx->n_cu * 8);
+        const size_t lds = (size_t)2 * F * sizeof(unsigned long long);
+        if (dtype == MSM_F32)
+            hipLaunchKernelGGL(column_minmax_kernel<float>, dim3(grid), dim3(256), lds, ctx->stream, (const float*)d_x, n, F, ld,
+                               gmin, gmax, (unsigned long long*)d_counts);
+        else
+            hipLaunchKernelGGL(column_minmax_kernel<double>, dim3(grid), dim3(256), lds, ctx->stream, (const double*)d_x, n, F, ld,
+                               gmin, gmax, (unsigned long long*)d_counts);
+        MSM_CHECK_LAUNCH(ctx);
+    }
+    hipLaunchKernelGGL(column_minmax_finish_kernel, dim3((F + 63) / 64), dim3(64), 0, ctx->stream, gmin, gmax, F, d_min, d_max);
     MSM_CHECK_LAUNCH(ctx);
     return MSM_OK;
 }
