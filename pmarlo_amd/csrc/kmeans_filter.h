@@ -48,7 +48,9 @@
 // 64 frames: tile loop (matrix pipe + top-two bookkeeping), the loads of the next unit's images and of this unit's
 // coordinates, the cross-lane step, the candidate pick, the commit, step 4 for what is left.  (Step 4 as a scan of all
 // centres in fp64, rows from global memory, cost 25-30 us per pass for 0.2 % of the frames, in place or queued for the
-// end of the workgroup's units alike: ~10 us of a wave per frame, and the slowest workgroup has 20 of them.)  What the SIMD can do (tools/probe/bf16_mix_probe.hip): a matrix instruction keeps the
+// end of the workgroup's units alike: ~10 us of a wave per frame, and the slowest workgroup has 20 of them.  Scoring
+// the eight candidates in fp64 before step 4, one lane and one row at a time, halves the frames that reach step 4 and
+// still loses 6 us per pass: eight dependent trips to the L2 per occurrence.)  What the SIMD can do (tools/probe/bf16_mix_probe.hip): a matrix instruction keeps the
 // matrix pipe for 16 cycles and the VALU port for 8, a VALU instruction the port for 4; the tile loop (16 + 34 per
 // iteration) is balanced between the two.  Tried and dropped: scoring the candidates of unit i - 1 inside the tile
 // loop of unit i (same time: the port is the limit either way, and the state costs 12 of 16 waves).
