@@ -13,6 +13,10 @@
 #include "common.h"
 #include "small_eig.h"
 
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+
 namespace {
 
 constexpr int kThreads = 256;
@@ -164,6 +168,7 @@ struct SpecArgs {
     // leading left Ritz vectors (optional)
     double* vecs;         // [batch][n_vecs][n_fixed]
     int n_vecs;
+    const int* persist_error;   // set by spec_persist_kernel when a group barrier timed out (NULL: not used)
 };
 
 // Batches converge unevenly (a lag scan, posterior samples): once a matrix has met the caller's
@@ -413,6 +418,205 @@ __device__ void spec_cholesky(SpecShared* sh, int p) {
     __syncthreads();
 }
 
+
+// ---- persistent driver: the subspace iterations of a matrix inside ONE launch ------------------------------
+// The loop above is two latency-bound launches per iteration (~77 us at n = 500: 3.9 ms for 50 iterations, 1.5 s for
+// the 5000 matrices of a lag scan with posterior samples).  Here a GROUP of G workgroups owns a matrix for all its
+// iterations: member r keeps columns J_r of T (= rows of T') in its LDS, so  W[J_r, :] = T[:, J_r]' Z  needs no
+// partial sums across workgroups; per iteration the members exchange their rows of W and the p x p Gram partials
+// through the L2 behind ONE barrier of the group; every member then sums the Gram partials in member order,
+// factorises the same p x p matrix and orthonormalises all of W itself (identical bits on all members, no broadcast).
+// Groups are resident together (cooperative launch) and placed on ONE XCD each (workgroup ids that differ by
+// multiples of 8 share an XCD: the barriers and the exchanged rows stay in that XCD's L2); a group works through the
+// matrices q, q + groups, ... of the batch (used for small batches only: see msm_spectrum).  A barrier that is not met
+// within ~1 s raises an error flag instead of spinning for ever.
+struct PersistArgs {
+    double* gram;          // [groups][2][G][kMaxP * kMaxP] Gram partials of odd / even steps
+    unsigned* counters;    // [groups] arrivals (monotonic)
+    int* error;            // [1]
+    int G, groups, cols, batch, n_iter;
+    double* bufA;          // [batch] basis in / out (zw_stride apart)
+    double* bufB;          // [batch] the other basis buffer
+};
+
+// The members of a group share ONE L2 (same XCD), so what a barrier must add to the arrival counter is: my stores have
+// left the CU (s_waitcnt: the vector L1 writes through) and, after the wait, my CU's L1 holds nothing stale
+// (buffer_inv sc1).  An agent-scope release would also write the L2 back to memory (buffer_wbl2) for readers on other
+// XCDs: ~20 us per barrier, none of which this exchange needs.
+__device__ __forceinline__ void group_barrier(unsigned* ctr, unsigned G, unsigned& epoch, int* error) {
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // every wave: its own stores have left the CU
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        epoch += 1;
+        __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        unsigned spins = 0;
+        while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < epoch * G) {
+            __builtin_amdgcn_s_sleep(1);
+            if (++spins > 40000000u) {
+                atomicExch(error, 1);
+                break;
+            }
+        }
+        asm volatile("buffer_inv sc1\n\ts_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __syncthreads();
+}
+
+struct PersistShared {     // (SpecShared carries 49 KB of Rayleigh-Ritz work space this kernel has no use for)
+    double G[kMaxP * kMaxP];
+    double R[kMaxP * kMaxP];
+    double Rinv[kMaxP * kMaxP];
+};
+
+// Cholesky factor R (upper, G = R'R) of the p x p Gram matrix by one wave, as spec_cholesky
+__device__ __forceinline__ void persist_cholesky(PersistShared* sh, int p) {
+    const int tid = threadIdx.x;
+    if (tid < 64) {
+        const int j = tid;
+        for (int c = 0; c < p; ++c) {
+            double v = 0.0;
+            if (j < p && j >= c) {
+                v = sh->G[c * p + j];
+                for (int m = 0; m < c; ++m) v = fma(-sh->R[m * p + c], sh->R[m * p + j], v);
+            }
+            double diag = __shfl(v, c, 64);
+            if (!(diag > 1e-300)) diag = 1e-300;  // rank-deficient basis: keep going, column dies out
+            const double rcc = sqrt(diag);
+            if (j < p) sh->R[c * p + j] = j > c ? v / rcc : (j == c ? rcc : 0.0);
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(kSolveThreads) void spec_persist_kernel(SpecArgs ar, PersistArgs pa) {
+    extern __shared__ __attribute__((aligned(16))) double plds[];
+    __shared__ PersistShared sh;
+    const int tid = threadIdx.x;
+    // workgroup id -> (group q, member r): ids that differ by multiples of 8 share an XCD, so group q lives on XCD
+    // q % 8 and its members are the ids  ((q / 8) G + r) 8 + q % 8
+    const int xcd = blockIdx.x % 8, t = blockIdx.x / 8;
+    const int q = (t / pa.G) * 8 + xcd, r = t % pa.G;
+    if (q >= pa.groups) return;       // ids of the padded grid without a group
+    unsigned* ctr = pa.counters + q;
+    unsigned epoch = 0;
+    const int n_max = ar.n_fixed;
+    const int ldt = pa.cols | 1, ldz = ar.p | 1;         // odd row strides: the lanes of a wave read 32 different rows
+    double* Tl = plds;                                   // [n][ldt]
+    double* Zl = Tl + (size_t)n_max * ldt;               // [n][ldz]
+    double* Wl = Zl + (size_t)n_max * ldz;               // [cols][p]
+    for (int b = q; b < pa.batch; b += pa.groups) {
+        const int n = ar.n_ptr ? ar.n_ptr[b] : ar.n_fixed;
+        if (n <= 0 || spec_frozen(ar, b)) continue;      // the same decision on every member
+        const int p = min(ar.p, n);
+        const double* T = ar.T + (size_t)b * ar.t_stride;
+        const int j0 = r * pa.cols, nj = max(0, min(n, j0 + pa.cols) - j0);
+        // this member's columns of T
+        for (int e = tid; e < n * pa.cols; e += kSolveThreads) {
+            const int i = e / pa.cols, jj = e - i * pa.cols;
+            Tl[i * ldt + jj] = jj < nj ? T[(size_t)i * ar.ld + j0 + jj] : 0.0;
+        }
+        double* zbuf = pa.bufA + (size_t)b * ar.zw_stride;          // orthonormal basis in, orthonormal basis out
+        double* wbuf[2] = {pa.bufB + (size_t)b * ar.zw_stride, zbuf};   // the exchanged (un-normalised) W of odd / even steps
+        double* gram = pa.gram + (size_t)q * 2 * pa.G * (kMaxP * kMaxP);
+        for (int e = tid; e < n * p; e += kSolveThreads) {
+            const int i = e / p;
+            Zl[i * ldz + (e - i * p)] = zbuf[e];
+        }
+        __syncthreads();
+        // One barrier per iteration: the members exchange their rows of W = T'Z (NOT yet orthonormal) and their Gram
+        // partials together; behind the barrier every member has all of W and the whole Gram matrix, factorises it and
+        // forms the orthonormal Z = W R^-1 for ALL rows itself (n p^2 flops: nothing) before its next product.
+        for (int it = 0; it < pa.n_iter; ++it) {
+            // W[jj][c] = sum_i T[i][j0 + jj] Z[i][c]: tiles of 2 x 4 outputs; the 32 lanes of a half wave take the rows
+            // i = lane, lane + 32, ... of one tile and add up by shuffles in a fixed order
+            {
+                const int tj = (pa.cols + 1) / 2, tc = (p + 3) / 4, tiles = tj * tc;
+                const int sp = tid & 31;
+                for (int tile = tid >> 5; tile < tiles; tile += kSolveThreads / 32) {
+                    double acc[2][4] = {{0.0, 0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 0.0}};
+                    const int jj0 = (tile / tc) * 2, c0 = (tile % tc) * 4;
+                    const bool two = jj0 + 1 < pa.cols;
+                    for (int i = sp; i < n; i += 32) {
+                        const double t0 = Tl[i * ldt + jj0], t1 = two ? Tl[i * ldt + jj0 + 1] : 0.0;
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) {
+                            const double z = c0 + c < p ? Zl[i * ldz + c0 + c] : 0.0;
+                            acc[0][c] = fma(t0, z, acc[0][c]);
+                            acc[1][c] = fma(t1, z, acc[1][c]);
+                        }
+                    }
+#pragma unroll
+                    for (int a = 0; a < 2; ++a)
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) {
+                            double v = acc[a][c];
+#pragma unroll
+                            for (int off = 1; off < 32; off <<= 1) v += __shfl_xor(v, off, 64);
+                            const int jj = jj0 + a, cc = c0 + c;
+                            if (sp == 0 && jj < pa.cols && cc < p) Wl[jj * p + cc] = jj < nj ? v : 0.0;
+                        }
+                }
+            }
+            __syncthreads();
+            double* wx = wbuf[it & 1];
+            double* gx = gram + (size_t)(it & 1) * pa.G * (kMaxP * kMaxP);
+            for (int e = tid; e < nj * p; e += kSolveThreads) wx[(size_t)j0 * p + e] = Wl[e];
+            for (int e = tid; e < p * p; e += kSolveThreads) {
+                const int a = e / p, c = e - a * p;
+                double v = 0.0;
+                for (int jj = 0; jj < nj; ++jj) v = fma(Wl[jj * p + a], Wl[jj * p + c], v);
+                gx[(size_t)r * (kMaxP * kMaxP) + e] = v;
+            }
+            group_barrier(ctr, pa.G, epoch, pa.error);
+            for (int e = tid; e < n * p; e += kSolveThreads) {
+                const int i = e / p;
+                Zl[i * ldz + (e - i * p)] = wx[e];
+            }
+            for (int e = tid; e < p * p; e += kSolveThreads) {
+                double v = 0.0;
+                for (int m = 0; m < pa.G; ++m) v += gx[(size_t)m * (kMaxP * kMaxP) + e];   // member order: the same bits everywhere
+                sh.G[e] = v;
+            }
+            __syncthreads();
+            persist_cholesky(&sh, p);
+            double* Rinv = sh.Rinv;     // R^-1 by one wave (lane = column)
+            if (tid < 64) {
+                const int c = tid;
+                if (c < p) {
+                    for (int m = 0; m < p; ++m) Rinv[m * p + c] = 0.0;
+                    Rinv[c * p + c] = 1.0 / sh.R[c * p + c];
+                    for (int m = c - 1; m >= 0; --m) {
+                        double a = 0.0;
+                        for (int l = m + 1; l <= c; ++l) a = fma(sh.R[m * p + l], Rinv[l * p + c], a);
+                        Rinv[m * p + c] = -a / sh.R[m * p + m];
+                    }
+                }
+            }
+            __syncthreads();
+            // Z = W R^-1, row by row in place (a thread owns a row: no hazard)
+            for (int i = tid; i < n; i += kSolveThreads) {
+                double w[kMaxP];
+#pragma unroll
+                for (int m = 0; m < kMaxP; ++m) w[m] = m < p ? Zl[i * ldz + m] : 0.0;
+                for (int c = 0; c < p; ++c) {
+                    double v = 0.0;
+                    for (int m = 0; m <= c; ++m) v = fma(w[m], Rinv[m * p + c], v);
+                    Zl[i * ldz + c] = v;
+                }
+            }
+            __syncthreads();
+        }
+        // the finishing launch expects the orthonormal basis in bufA; the last exchange may still be read from there
+        group_barrier(ctr, pa.G, epoch, pa.error);
+        for (int e = tid; e < nj * p; e += kSolveThreads) {
+            const int jj = e / p;
+            zbuf[(size_t)j0 * p + e] = Zl[(j0 + jj) * ldz + (e - jj * p)];
+        }
+        group_barrier(ctr, pa.G, epoch, pa.error);   // nobody overwrites Tl / the Gram partials of a matrix still in use
+    }
+}
+
 // Z: current (orthonormal unless between orthogonalisations) basis; Wb: the other buffer.
 template <bool lds_w>
 __global__ __launch_bounds__(kSolveThreads) void spec_step_kernel(SpecArgs ar, int mode, double* __restrict__ Zall,
@@ -521,8 +725,30 @@ __global__ __launch_bounds__(kSolveThreads) void spec_step_kernel(SpecArgs ar, i
     // Convergence measure: the true residual ||T'x - theta x|| / ||x|| of every watched REAL
     // Ritz pair (x = Z y, T'x = W y); for complex values, the change since the last check.
     // (Changes of Ritz values alone stagnate on clustered spectra and would stop too early.)
+    // The Ritz vectors these steps need (one per watched real Ritz value, one for the stationary distribution) are
+    // inverse iterations of ~50 us each by ONE wave: when their work space fits they run side by side on separate
+    // waves (7 vectors at p = 12: 0.43 -> 0.1 ms for this launch); wider subspaces take them one after the other.
+    const int nw = min(ar.n_watch, p);
+    const int per = p * p + 3 * p;                          // [y p | work p p + 2 p] of one inverse iteration
+    const bool side_by_side = (nw + 1) * per <= 3 * kMaxP * kMaxP && nw + 1 <= (int)(blockDim.x >> 6);
+    int pi_id = 0;
     {
-        const int nw = min(ar.n_watch, p);
+        double bd = 1e300;
+        for (int i = 0; i < p; ++i) {
+            const double dr = sh.wr[i] - 1.0, di = sh.wi[i];
+            const double dd = dr * dr + di * di;
+            if (dd < bd) { bd = dd; pi_id = i; }
+        }
+    }
+    if (side_by_side) {
+        const int w = tid >> 6;
+        if (w < nw && ritz[kMaxP + w] == 0.0)
+            small_eig::eigenvector_wave(sh.H, p, p, ritz[w], sh.Hw + w * per, sh.Hw + w * per + p);
+        else if (w == nw && ar.pi)
+            small_eig::eigenvector_wave(sh.H, p, p, sh.wr[pi_id], sh.Hw + w * per, sh.Hw + w * per + p);
+        __syncthreads();
+    }
+    {
         double worst = 0.0;
         for (int wv = 0; wv < nw; ++wv) {
             const double th_re = ritz[wv], th_im = ritz[kMaxP + wv];
@@ -533,14 +759,18 @@ __global__ __launch_bounds__(kSolveThreads) void spec_step_kernel(SpecArgs ar, i
                 worst = fmax(worst, ch);
                 continue;
             }
-            if (tid < 64) small_eig::eigenvector_wave(sh.H, p, p, th_re, sh.y, sh.Hw);
-            __syncthreads();
+            const double* yv = sh.y;
+            if (side_by_side) yv = sh.Hw + wv * per;
+            else {
+                if (tid < 64) small_eig::eigenvector_wave(sh.H, p, p, th_re, sh.y, sh.Hw);
+                __syncthreads();
+            }
             double rn = 0.0, xn = 0.0;
             for (int i = tid; i < n; i += blockDim.x) {
                 double xv = 0.0, tv = 0.0;
                 for (int c = 0; c < p; ++c) {
-                    xv = fma(Z[(size_t)i * p + c], sh.y[c], xv);
-                    tv = fma(W[(size_t)i * p + c], sh.y[c], tv);
+                    xv = fma(Z[(size_t)i * p + c], yv[c], xv);
+                    tv = fma(W[(size_t)i * p + c], yv[c], tv);
                 }
                 const double r = tv - th_re * xv;
                 rn = fma(r, r, rn);
@@ -555,28 +785,24 @@ __global__ __launch_bounds__(kSolveThreads) void spec_step_kernel(SpecArgs ar, i
     __syncthreads();
     // stationary distribution: Ritz vector of the eigenvalue nearest 1
     if (ar.pi) {
-        if (tid < 64) {
-            int best = 0;
-            double bd = 1e300;
-            for (int i = 0; i < p; ++i) {
-                const double dr = sh.wr[i] - 1.0, di = sh.wi[i];
-                const double dd = dr * dr + di * di;
-                if (dd < bd) { bd = dd; best = i; }
-            }
-            small_eig::eigenvector_wave(sh.H, p, p, sh.wr[best], sh.y, sh.Hw);
+        const double* yv = sh.y;
+        if (side_by_side) yv = sh.Hw + nw * per;
+        else {
+            if (tid < 64) small_eig::eigenvector_wave(sh.H, p, p, sh.wr[pi_id], sh.y, sh.Hw);
+            __syncthreads();
         }
-        __syncthreads();
         double* pi = ar.pi + (size_t)b * ar.pi_stride;
         double part = 0.0;
         for (int i = tid; i < n; i += blockDim.x) {
             double v = 0.0;
-            for (int c = 0; c < p; ++c) v = fma(Z[(size_t)i * p + c], sh.y[c], v);
+            for (int c = 0; c < p; ++c) v = fma(Z[(size_t)i * p + c], yv[c], v);
             pi[i] = v;
             part += v;
         }
         const double tot = spec_block_sum(part, &sh);
         for (int i = tid; i < n; i += blockDim.x) pi[i] = pi[i] / tot;
     }
+    __syncthreads();
     // leading left eigenvectors (x' T = theta x'), Ritz values by descending magnitude (the order
     // deeptime's eigenvectors() returns); unit 2-norm, the component of largest magnitude (lowest
     // index on ties) positive; NaN for a complex pair or beyond the subspace
@@ -648,6 +874,7 @@ __global__ __launch_bounds__(kSolveThreads) void spec_step_kernel(SpecArgs ar, i
         }
     }
     if (tid == 0 && sh.status) ar.status[b] = sh.status;
+    if (tid == 0 && ar.persist_error && *ar.persist_error) ar.status[b] = 777;   // a group barrier of the persistent launch timed out
 }
 
 }  // namespace
@@ -703,6 +930,14 @@ msm_status msm_embed_full(msm_ctx* ctx, const double* d_T_active, const double* 
     return MSM_OK;
 }
 
+static bool spec_persist_enabled() {
+    static const bool on = [] {
+        const char* e = getenv("MSM_SPEC_PERSIST");   // MSM_SPEC_PERSIST=0: the launch-per-iteration loop (A/B timing)
+        return !(e && e[0] == '0');
+    }();
+    return on;
+}
+
 size_t msm_spectrum_workspace_bytes(int n_max, int p, int batch) {
     // two basis buffers (+ reduction scratch tail) and the row-split partial products
     const size_t per = (2 * ((size_t)n_max * p + kSolveThreads) + (size_t)kSpecSplits * n_max * p) * sizeof(double);
@@ -736,6 +971,7 @@ msm_status msm_spectrum(msm_ctx* ctx, const double* d_T, int64_t t_stride, int l
     ar.freeze_tol = freeze_tol;
     ar.vecs = d_vecs; ar.n_vecs = n_vecs;
     ar.status = d_status; ar.n_its = n_its; ar.lags = d_lags; ar.its_eig = d_its_eig; ar.its_ts = d_its_ts;
+    ar.persist_error = nullptr;
     // orthogonalise every kOrthoEvery applications and always after the last one; compare the
     // complex Ritz values against those right after an earlier orthogonalisation.  Every step:
     // Cholesky-QR squares the condition number of W, and a metastable T damps the fast directions
@@ -766,10 +1002,59 @@ msm_status msm_spectrum(msm_ctx* ctx, const double* d_T, int64_t t_stride, int l
         MSM_HIP(ctx, hipMemsetAsync(d_status, 0, sizeof(int32_t) * batch, ctx->stream));
     if (init) step(kStepInit, bufA, bufB);
     MSM_CHECK_LAUNCH(ctx);
+    // ---- the iterations: one persistent launch when the shape allows (see spec_persist_kernel)
+    bool persisted = false;
+    if (n_iter > 0 && spec_persist_enabled()) {
+        const size_t budget = (size_t)(160 - 24 - 4) * 1024 / sizeof(double);   // LDS less PersistShared and slack
+        const size_t fixed = (size_t)n_max * (p | 1);
+        int cols = budget > fixed + (size_t)8 * (n_max + p + 2) ? (int)((budget - fixed) / (size_t)(n_max + p + 2)) : 0;
+        cols = std::min(cols, n_max);
+        auto fits = [&](int c) { return (size_t)n_max * (c | 1) + fixed + (size_t)c * p <= budget; };
+        while (cols >= 8 && !fits(cols)) --cols;
+        if (getenv("MSM_SPEC_DEBUG")) fprintf(stderr, "msm_spectrum: n=%d p=%d first cols=%d\n", n_max, p, cols);
+        if (cols >= 8) {
+            const int G = (n_max + cols - 1) / cols;
+            while (cols > 1 && (n_max + cols - 2) / (cols - 1) == G && fits(cols - 1)) --cols;   // even shares: the fewest columns that keep G
+            // a group lives on one XCD (32 CUs): G <= 32; groups per XCD = 32 / G, eight XCDs
+            const int per_xcd = G <= 32 ? 32 / G : 0;
+            // Only when every matrix gets a group at once: a large batch (a lag scan with posterior samples) already
+            // fills the chip with independent single-workgroup steps, and a group per matrix would serialise it.
+            const int groups = batch <= 8 * per_xcd ? batch : 0;
+            if (groups >= 1) {
+                const int slots = (groups + 7) / 8;          // group q = slot * 8 + xcd
+                const size_t gram_bytes = (size_t)groups * 2 * G * kMaxP * kMaxP * sizeof(double);
+                const size_t need = gram_bytes + (size_t)groups * sizeof(unsigned) + 64;
+                msm_status rs = msm_reserve_aux(ctx, need);
+                if (rs != MSM_OK) return rs;
+                PersistArgs pa;
+                pa.gram = (double*)ctx->aux;
+                pa.counters = (unsigned*)((char*)ctx->aux + gram_bytes);
+                pa.error = (int*)(pa.counters + groups);
+                pa.G = G; pa.groups = groups; pa.cols = cols; pa.batch = batch; pa.n_iter = n_iter;
+                pa.bufA = bufA; pa.bufB = bufB;
+                MSM_HIP(ctx, hipMemsetAsync(pa.counters, 0, (size_t)groups * sizeof(unsigned) + sizeof(int), ctx->stream));
+                const size_t lds = ((size_t)n_max * (cols | 1) + (size_t)n_max * (p | 1) + (size_t)cols * p) * sizeof(double);
+                MSM_HIP(ctx, hipFuncSetAttribute((const void*)spec_persist_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                 (int)lds));
+                void* kargs[] = {(void*)&ar, (void*)&pa};
+                hipError_t le = hipLaunchCooperativeKernel((const void*)spec_persist_kernel, dim3((unsigned)(slots * G * 8)),
+                                                           dim3(kSolveThreads), kargs, (unsigned)lds, ctx->stream);
+                if (getenv("MSM_SPEC_DEBUG"))
+                    fprintf(stderr, "msm_spectrum: persistent launch n=%d p=%d cols=%d G=%d groups=%d lds=%zu -> %s\n", n_max, p,
+                            cols, G, groups, lds, hipGetErrorString(le));
+                if (le == hipSuccess) {
+                    persisted = true;
+                    ar.persist_error = pa.error;
+                } else {
+                    (void)hipGetLastError();     // not resident together on this device / in this state: the launch loop below
+                }
+            }
+        }
+    }
     // invariant at the top of an iteration: the current basis is in `cur`
     double* cur = bufA;
     double* other = bufB;
-    for (int it = 0; it < n_iter; ++it) {
+    for (int it = 0; it < (persisted ? 0 : n_iter); ++it) {
         apply(cur);
         const bool ortho = (it % kOrthoEvery) == kOrthoEvery - 1 || it == n_iter - 1;
         const int mode = ortho ? kStepOrtho : 0;

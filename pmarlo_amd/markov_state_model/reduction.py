@@ -50,14 +50,77 @@ def tica_reduce(X: np.ndarray, lag: int = 1, n_components: int = 2, scale: bool 
     return np.ascontiguousarray(pipe.tica_transform(model, xd).to_host(), dtype=float)
 
 
+def _gen_batches(n: int, batch_size: int, min_batch_size: int):
+    """sklearn.utils.gen_batches: slices of batch_size, a short tail merged into the last slice."""
+    start = 0
+    for _ in range(int(n // batch_size)):
+        end = start + batch_size
+        if end + min_batch_size > n:
+            continue
+        yield start, end
+        start = end
+    if start < n:
+        yield start, n
+
+
+def _incremental_pca(eng, pipe, xd, n: int, F: int, n_components: int, batch_size: int, mu, sigma, inv_sigma, has_nan):
+    """sklearn IncrementalPCA(n_components, batch_size).fit_transform on the preprocessed data, batch by batch as
+    partial_fit does (S/markov_state_model/reduction.py:69-73): the SVD of
+    [singular values x components | centred batch | mean correction] is taken through its F x F Gram matrix --
+    the batch's second moments come from the matrix-core moments kernel (one segment per batch, the frames stay on the
+    device), the F x F eigenproblem from the device Jacobi solver; signs as svd_flip(u_based_decision=False)."""
+    sd = sigma.to_host()
+    comps = np.zeros((0, F))
+    sv = np.zeros((0,))
+    mean = np.zeros(F)
+    seen = 0
+    for a, b in _gen_batches(n, batch_size, n_components):
+        mom = pipe.tica_moments(xd, 0, mu, segments=[(a, b)], assume_finite=not has_nan, symmetric=True).to_host()
+        nb = b - a
+        S = 0.5 * mom[:F * F].reshape(F, F) / np.outer(sd, sd)          # sum z z' of the batch
+        sz = mom[2 * F * F:2 * F * F + F] / sd                            # sum z
+        mb = sz / nb
+        total = seen + nb
+        gram = S - nb * np.outer(mb, mb)                                  # centred about the batch mean
+        if seen:
+            corr = np.sqrt((seen / total) * nb) * (mean - mb)
+            gram = gram + (comps.T * (sv ** 2)) @ comps + np.outer(corr, corr)
+        gram = 0.5 * (gram + gram.T)
+        w, V, _ = eng.eigh(eng.to_device(np.ascontiguousarray(gram)))
+        w, V = w.to_host(), V.to_host()
+        order = np.argsort(-w, kind="stable")[:n_components]
+        vt = V[:, order].T
+        vt = vt * np.sign(vt[np.arange(vt.shape[0]), np.argmax(np.abs(vt), axis=1)])[:, None]
+        comps, sv = vt, np.sqrt(np.maximum(w[order], 0.0))
+        mean = (seen * mean + sz) / total
+        seen = total
+    Wfull = np.zeros((F, F))
+    Wfull[:, :n_components] = comps.T
+    Y = eng.project(xd, mu, inv_sigma, eng.to_device(Wfull), n_components, mean2=eng.to_device(mean))
+    return np.asarray(Y.to_host(), dtype=float)
+
+
 def pca_reduce(X: np.ndarray, n_components: int = 2, batch_size: Optional[int] = None, scale: bool = True) -> np.ndarray:
     """_preprocess + sklearn PCA(n_components).fit_transform (S/markov_state_model/reduction.py:43-74) on the
     GPU: second moments on the matrix cores (lag 0), Jacobi eigendecomposition of the F x F covariance
     (sklearn's covariance_eigh solver: ddof = 1, components by descending variance, each component's
-    largest-magnitude loading made positive), projection on the matrix cores.  ``batch_size``
-    (IncrementalPCA) is not available."""
+    largest-magnitude loading made positive), projection on the matrix cores.  With ``batch_size`` the reference
+    switches to IncrementalPCA: `_incremental_pca` walks the same batches."""
     if batch_size is not None:
-        raise NotImplementedError("IncrementalPCA (batch_size) is outside the accelerated path")
+        Xm = _as_matrix(X)
+        n, F = Xm.shape
+        n_components, batch_size = int(n_components), int(batch_size)
+        if not 1 <= n_components <= F:
+            raise ValueError(f"n_components={n_components} invalid for n_features={F}, need more rows than columns for "
+                             "IncrementalPCA processing")
+        if n_components > batch_size or n_components > n:
+            raise ValueError(f"n_components={n_components} must be less or equal to the batch number of samples "
+                             f"{min(batch_size, n)}")
+        eng = get_engine()
+        pipe = MSMPipeline(eng)
+        xd = eng.to_device(Xm)
+        mu, sigma, inv_sigma, has_nan = pipe.standardise_params(xd, scale=scale)
+        return _incremental_pca(eng, pipe, xd, n, F, n_components, batch_size, mu, sigma, inv_sigma, has_nan)
     Xm = _as_matrix(X)
     n, F = Xm.shape
     n_components = int(n_components)

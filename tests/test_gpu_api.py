@@ -412,8 +412,6 @@ def test_pca_reduce_vs_reference_golden_and_oracle(engine, golden):
     got = reduce_features(X, method="pca", n_components=4)
     want = npport.pca_reduce(X.astype(np.float64), 4)
     np.testing.assert_allclose(got, want, rtol=0, atol=1e-8 * np.abs(want).max())
-    with pytest.raises(NotImplementedError):
-        pca_reduce(X[:100], batch_size=10)
     with pytest.raises(ValueError):
         reduce_features(X[:100], method="umap")
     with pytest.raises(ValueError):
@@ -488,3 +486,24 @@ def test_device_view_keeps_its_allocation_alive(engine):
     np.testing.assert_array_equal(view.to_host(), np.arange(512, 528, dtype=np.float64))
     np.testing.assert_array_equal(chained.to_host(), np.arange(520, 524, dtype=np.float64))
     del junk
+
+
+def test_pca_reduce_with_batches_equals_incremental_pca(engine):
+    """pca_reduce(batch_size=...) = _preprocess + sklearn IncrementalPCA(n_components, batch_size).fit_transform
+    (S/markov_state_model/reduction.py:69-73), batch by batch on the device: against sklearn itself on the same
+    preprocessed data (the restated _preprocess is pinned by the golden fixtures)."""
+    from sklearn.decomposition import IncrementalPCA
+
+    from pmarlo_amd.markov_state_model import pca_reduce
+
+    rng = np.random.default_rng(4)
+    X = _gen.correlated_series(12_345, 16, seed=8).astype(np.float64) * rng.uniform(0.5, 20.0, size=16) + rng.normal(size=16)
+    X[17, 3] = np.nan                                   # imputed by the column mean in _preprocess
+    for batch, k, scale in ((1000, 4, True), (4096, 3, False), (12_345, 5, True), (777, 16, True)):
+        got = pca_reduce(X, n_components=k, batch_size=batch, scale=scale)
+        Xp = npport.preprocess(X, scale=scale)
+        want = IncrementalPCA(n_components=k, batch_size=batch).fit_transform(Xp.copy())
+        assert got.shape == want.shape
+        np.testing.assert_allclose(got, want, rtol=0, atol=2e-7 * np.abs(want).max())
+    with pytest.raises(ValueError):
+        pca_reduce(X[:100], n_components=12, batch_size=10)

@@ -21,4 +21,7 @@ for name, lab in cases.items():
     d = eng.to_device(lab)
     out = eng.zeros((k, k), np.int64)
     med, mn = timeit(eng, lambda: eng.count_transitions(d, k, lag, out=out))
-    print(f"{name:10s} median {med*1e3:8.1f} us  min {mn*1e3:8.1f} us")
+    ref = np.zeros((k, k), np.int64)
+    np.add.at(ref, (lab[:-lag], lab[lag:]), 1)
+    ok = np.array_equal(out.to_host(), ref)
+    print(f"{name:10s} median {med*1e3:8.1f} us  min {mn*1e3:8.1f} us  exact={ok}")
