@@ -183,8 +183,9 @@ def kernel_rooflines(eng, msm, c: dict, n: int, acc_ms: float) -> list:
     if not msm.cfg.lags:
         ms = med(lambda: eng.count_transitions(msm.labels, k, lag, out=b["counts"].view((k, k)),
                                                pairs=b["counts"].view((1,), offset_elems=k * k)))
-        row("count kernel (+ memset of the k x k matrix)", ms, "hbm", alg_bytes=float(4 * n + 8 * k * k),
-            note="4 B label per frame + the int64 matrix once; atomics, not bandwidth, set the pace")
+        row("count_bucket_scatter_kernel + count_bucket_bin_kernel", ms, "hbm", alg_bytes=float(4 * n + 8 * k * k),
+            note="4 B label per frame + the int64 matrix once; two launches, no global atomics: latency of the two "
+                 "short launches, not bandwidth, sets the pace")
     return out
 
 

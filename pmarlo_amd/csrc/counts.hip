@@ -8,8 +8,12 @@
 // its row block with LDS atomics, and flushes only the non-zero bins into the
 // int64 matrix with global atomics.  Integer adds commute, so the result is
 // bit-exact and independent of scheduling.  When even 16 rows do not fit (very
-// large k) the kernel degenerates to direct global atomics.
+// large k) the kernel degenerates to direct global atomics.  Unweighted counts with
+// at least as many pairs as bins (the bench shape) take the two-pass bucket path
+// further down instead: no global atomics at all.
 #include "common.h"
+
+#include <cstdlib>
 
 namespace {
 
@@ -104,6 +108,213 @@ __global__ __launch_bounds__(kThreads) void count_lds_kernel(
     if (pairs_out) block_add_u64(local_pairs, pairs_out);
 }
 
+
+// ---- bucket path (unweighted, dense regime: at least as many pairs as bins) --------------------------------------------
+// The LDS-privatised kernel above still ends in one 64-bit global atomic per non-empty (workgroup, bin), and at C3
+// (1 M pairs, 250 k bins) that is most of its time and most of its HBM traffic: a device-scope atomic is resolved behind
+// the L2s (64 B of traffic each, ~16 G atomics/s over the whole chip, measured), and so are atomics into per-XCD private
+// copies of the matrix (tried: 60 us random labels, 1.4 ms when every pair hits one bin).  This path has NO global
+// atomics on the matrix.
+//   Pass 1: a workgroup counts the DISTINCT pairs of its chunk in an LDS hash table (a trajectory dwells: a chunk of
+//   consecutive frames holds few distinct pairs), groups them by bucket of source rows and writes them out as 16-bit
+//   elements with its table of group offsets.  Element stream of a group: a key alone (the pair was seen once) or a key
+//   with the `multi` flag followed by a count element.
+//   Pass 2: workgroup b OWNS the rows of bucket b, gathers its groups from all chunks, bins them in LDS and stores its
+//   rows of the int64 matrix once.
+// Integer adds only: exact and independent of scheduling.  HBM traffic at C3 with no repeated pairs at all: labels 4 MB
+// + elements 2 MB out and in + offsets 0.5 MB + matrix 2 MB = 10.5 MB (the privatised kernel: 26 MB).
+constexpr int kBucketsMax = 256;            // pass-2 workgroups (one per CU)
+constexpr int kChunkMax = 4096;             // pairs per pass-1 workgroup (hash table of 2 x chunk slots, 8 B each)
+constexpr int kBinCopiesBytes = 64 * 1024;  // LDS for the (wave-private) copies of a bucket's bins; R k <= 16384 keys
+constexpr unsigned kElemMulti = 0x8000u;    // key element: a count element follows
+constexpr unsigned kElemCount = 0x4000u;    // count element: count - 2 in the low bits (count <= kChunkMax)
+constexpr unsigned kSlotEmpty = 0xFFFFFFFFu;
+
+// exclusive prefix sum over the workgroup (kThreads values); total returned to every thread
+__device__ __forceinline__ unsigned block_excl_scan_u32(unsigned v, unsigned* total) {
+    __shared__ unsigned wave_tot[kThreads / 64 + 1];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    unsigned inc = v;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const unsigned o = __shfl_up(inc, off, 64);
+        if (lane >= off) inc += o;
+    }
+    __syncthreads();                       // wave_tot of a previous call is no longer read
+    if (lane == 63) wave_tot[wave] = inc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned run = 0;
+        for (int w = 0; w < kThreads / 64; ++w) { const unsigned t = wave_tot[w]; wave_tot[w] = run; run += t; }
+        wave_tot[kThreads / 64] = run;
+    }
+    __syncthreads();
+    *total = wave_tot[kThreads / 64];
+    return wave_tot[wave] + inc - v;
+}
+
+// Pass 1.  grid = chunks.  elems: [chunks][chunk] uint16, offs: [buckets + 1][chunks] uint32 (transposed: pass 2 reads a
+// bucket's offsets of all chunks as one contiguous row).  slots: power of two >= 2 chunk.
+__global__ __launch_bounds__(kThreads) void count_bucket_scatter_kernel(const int32_t* __restrict__ labels, SegTab st, int k,
+                                                                       int R, int buckets, int chunk, int slots,
+                                                                       unsigned short* __restrict__ elems,
+                                                                       unsigned int* __restrict__ offs,
+                                                                       unsigned int* __restrict__ valid_out) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    unsigned int* tkey = reinterpret_cast<unsigned int*>(smem_raw);                  // [slots] pair id a k + b
+    unsigned int* tcnt = tkey + slots;                                               // [slots] times seen
+    unsigned int* hist = tcnt + slots;                                               // [kBucketsMax] then the write cursors
+    unsigned int* start = hist + kBucketsMax;                                        // [kBucketsMax + 1]
+    unsigned short* out = reinterpret_cast<unsigned short*>(start + kBucketsMax + 1 + 1);   // [chunk] elements by bucket
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int chunks = gridDim.x;
+    for (int i = tid; i < slots; i += kThreads) { tkey[i] = kSlotEmpty; tcnt[i] = 0; }
+    if (tid < kBucketsMax) hist[tid] = 0;
+    __syncthreads();
+    const int64_t p0 = (int64_t)blockIdx.x * chunk;
+    const int cnt = (int)max((int64_t)0, min((int64_t)chunk, st.total_pairs - p0));
+    const int lag = st.lag;
+    const unsigned mask = (unsigned)slots - 1u;
+    unsigned local_pairs = 0;
+    for (int i0 = 0; i0 < cnt; i0 += kThreads) {       // whole waves iterate together (wave-wide run detection below)
+        const int i = i0 + tid;
+        unsigned id = kSlotEmpty;
+        if (i < cnt) {
+            const int64_t t = seg_pair_to_frame(st, p0 + i);
+            const int a = labels[t], b = labels[t + lag];
+            if ((unsigned)a < (unsigned)k && (unsigned)b < (unsigned)k) { id = (unsigned)a * (unsigned)k + (unsigned)b; ++local_pairs; }
+        }
+        // neighbouring lanes with the same pair insert once: the first lane of a run carries the run length
+        const unsigned prev = __shfl_up(id, 1, 64);
+        const bool head = lane == 0 || id != prev;
+        const unsigned long long heads = __ballot(head);
+        if (head && id != kSlotEmpty) {
+            const unsigned long long above = (heads >> lane) >> 1;
+            const unsigned run = above ? (unsigned)__ffsll((long long)above) : (unsigned)(64 - lane);
+            unsigned h = (id * 2654435761u) >> 7 & mask;
+            for (;;) {      // at most `cnt` distinct ids in >= 2 cnt slots: an empty slot is always found
+                const unsigned was = atomicCAS(&tkey[h], kSlotEmpty, id);
+                if (was == kSlotEmpty || was == id) break;
+                h = (h + 1) & mask;
+            }
+            atomicAdd(&tcnt[h], run);
+        }
+    }
+    __syncthreads();
+    const unsigned rk = (unsigned)R * (unsigned)k;
+    for (int sidx = tid; sidx < slots; sidx += kThreads) {
+        const unsigned id = tkey[sidx];
+        if (id != kSlotEmpty) atomicAdd(&hist[id / rk], tcnt[sidx] > 1 ? 2u : 1u);
+    }
+    __syncthreads();
+    unsigned total;
+    const unsigned mine = tid < buckets ? hist[tid] : 0u;
+    const unsigned ex = block_excl_scan_u32(mine, &total);
+    if (tid < buckets) { start[tid] = ex; hist[tid] = ex; }
+    if (tid == buckets) start[tid] = total;
+    unsigned n_valid;
+    (void)block_excl_scan_u32(local_pairs, &n_valid);      // (also the barrier between `start` and its readers)
+    for (int sidx = tid; sidx < slots; sidx += kThreads) {
+        const unsigned id = tkey[sidx];
+        if (id == kSlotEmpty) continue;
+        const unsigned bk = id / rk, key = id - bk * rk, c = tcnt[sidx];
+        const unsigned pos = atomicAdd(&hist[bk], c > 1 ? 2u : 1u);
+        if (c > 1) {
+            out[pos] = (unsigned short)(key | kElemMulti);
+            out[pos + 1] = (unsigned short)(kElemCount | (c - 2));
+        } else {
+            out[pos] = (unsigned short)key;
+        }
+    }
+    __syncthreads();
+    // (the order inside a group depends on the scheduling of the LDS atomics; the counts do not)
+    unsigned int* dst = reinterpret_cast<unsigned int*>(elems + (size_t)blockIdx.x * chunk);     // chunk is even
+    const unsigned int* src = reinterpret_cast<const unsigned int*>(out);
+    for (int i = tid; i < (int)((total + 1) >> 1); i += kThreads) dst[i] = src[i];
+    if (tid <= buckets) offs[(size_t)tid * chunks + blockIdx.x] = start[tid];
+    if (tid == 0) valid_out[blockIdx.x] = n_valid;
+}
+
+// Pass 2.  grid = buckets; workgroup b owns the rows [b R, b R + R) of the matrix.
+__global__ __launch_bounds__(kThreads) void count_bucket_bin_kernel(const unsigned short* __restrict__ elems,
+                                                                   const unsigned int* __restrict__ offs, int chunks,
+                                                                   int chunk, int k, int R, int copies,
+                                                                   unsigned long long* __restrict__ counts,
+                                                                   const unsigned int* __restrict__ valid,
+                                                                   unsigned long long* __restrict__ pairs_out) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    const int nb = R * k;                                                  // bins of one copy
+    unsigned int* bins = reinterpret_cast<unsigned int*>(smem_raw);        // [copies][nb]
+    unsigned int* pref = bins + (size_t)copies * nb;                       // [kThreads + 1] group prefix of this tile
+    unsigned int* base = pref + kThreads + 1;                              // [kThreads] first element of the group in `elems`
+    const int tid = threadIdx.x;
+    const int b = blockIdx.x;
+    for (int i = tid; i < copies * nb; i += kThreads) bins[i] = 0;
+    unsigned int* my_bins = bins + (size_t)((tid >> 6) & (copies - 1)) * nb;   // copies is a power of two
+    for (int w0 = 0; w0 < chunks; w0 += kThreads) {
+        const int w = w0 + tid;
+        unsigned s = 0, len = 0;
+        if (w < chunks) {
+            s = offs[(size_t)b * chunks + w];
+            len = offs[(size_t)(b + 1) * chunks + w] - s;
+        }
+        unsigned total;
+        const unsigned ex = block_excl_scan_u32(len, &total);      // (its barriers also cover the zeroing above)
+        pref[tid] = ex;
+        base[tid] = (unsigned)w * (unsigned)chunk + s;             // chunks * chunk < 2^32 (launch_counts checks)
+        __syncthreads();
+        const int nseg = min(kThreads, chunks - w0);
+        constexpr int kU = 4;                                      // independent searches and loads in flight per lane
+        for (unsigned e0 = 0; e0 < total; e0 += kU * kThreads) {
+            unsigned key[kU], add[kU];
+#pragma unroll
+            for (int u = 0; u < kU; ++u) {
+                const unsigned e = e0 + u * kThreads + tid;
+                key[u] = 0;
+                add[u] = 0;
+                if (e < total) {
+                    int lo = 0, hi = nseg - 1;                     // last group with pref <= e
+                    while (lo < hi) {
+                        const int mid = (lo + hi + 1) >> 1;
+                        if (pref[mid] <= e) lo = mid; else hi = mid - 1;
+                    }
+                    const unsigned short* at = elems + (size_t)base[lo] + (e - pref[lo]);
+                    const unsigned v = at[0];
+                    if (!(v & kElemCount)) {                        // a count element is consumed with its key
+                        key[u] = v & (kElemCount - 1u);
+                        add[u] = (v & kElemMulti) ? (at[1] & (kElemCount - 1u)) + 2u : 1u;
+                    }
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < kU; ++u)
+                if (add[u]) atomicAdd(&my_bins[key[u]], add[u]);
+        }
+        __syncthreads();
+    }
+    const int r0 = b * R;
+    const int nrows = min(R, k - r0);
+    unsigned long long* dst = counts + (size_t)r0 * k;
+    for (int i = tid; i < nrows * k; i += kThreads) {
+        unsigned long long v = 0;
+        for (int c = 0; c < copies; ++c) v += bins[(size_t)c * nb + i];
+        dst[i] = v;
+    }
+    if (b == 0 && pairs_out) {         // number of counted pairs: the chunks' valid counts, no atomics, no memset
+        unsigned long long v = 0;
+        for (int w = tid; w < chunks; w += kThreads) v += valid[w];
+        __shared__ unsigned long long wave_part[kThreads / 64];
+        v = wave_sum_u64(v);
+        if ((tid & 63) == 0) wave_part[tid >> 6] = v;
+        __syncthreads();
+        if (tid == 0) {
+            unsigned long long t = 0;
+            for (int w = 0; w < kThreads / 64; ++w) t += wave_part[w];
+            *pairs_out = t;
+        }
+    }
+}
+
 // Very large k: no privatisation, one global atomic per pair.
 template <bool WEIGHTED>
 __global__ __launch_bounds__(kThreads) void count_global_kernel(
@@ -150,6 +361,14 @@ __global__ __launch_bounds__(kThreads) void state_counts_kernel(
     }
 }
 
+bool count_buckets_enabled() {
+    static const bool on = [] {
+        const char* e = getenv("MSM_COUNTS_BUCKETS");   // MSM_COUNTS_BUCKETS=0: the privatised kernel everywhere (A/B timing)
+        return !(e && e[0] == '0');
+    }();
+    return on;
+}
+
 struct CountPlan {
     bool global_path;
     int rows, row_blocks, chunks;
@@ -191,6 +410,40 @@ msm_status launch_counts(msm_ctx* ctx, const int32_t* d_labels, const double* d_
                          const SegTab& st, int k, void* d_counts, int64_t* d_pairs) {
     using out_t = typename BinT<WEIGHTED>::out_t;
     using lds_t = typename BinT<WEIGHTED>::lds_t;
+    if constexpr (!WEIGHTED) {
+        // dense regime, a bucket of rows fits the LDS: two passes without global atomics (see count_bucket_*)
+        const int R = msm_ceil_div(k, kBucketsMax), buckets = msm_ceil_div(k, R);
+        const size_t bin_bytes = (size_t)R * k * sizeof(unsigned int);
+        if (count_buckets_enabled() && bin_bytes <= (size_t)kBinCopiesBytes && st.total_pairs >= (int64_t)k * k &&
+            st.total_pairs < ((int64_t)1 << 31)) {
+            int chunk = (int)std::min<int64_t>(kChunkMax, std::max<int64_t>(2048, msm_ceil_div(st.total_pairs, ctx->n_cu)));
+            if (const char* e = getenv("MSM_COUNTS_CHUNK")) chunk = std::max(64, std::min(kChunkMax, atoi(e)));   // tests: many chunks at small n
+            chunk = (chunk + 63) & ~63;
+            const int chunks = msm_ceil_div(st.total_pairs, chunk);
+            int slots = 128;
+            while (slots < 2 * chunk) slots *= 2;
+            const size_t elem_bytes = ((size_t)chunks * chunk * sizeof(unsigned short) + 255) & ~(size_t)255;
+            const size_t need = elem_bytes + (size_t)(buckets + 2) * chunks * sizeof(unsigned int);
+            if (!(ctx->capturing && need > ctx->aux_bytes)) {      // (a capture cannot grow the scratch: privatised kernel)
+                msm_status rs = msm_reserve_aux(ctx, need);
+                if (rs != MSM_OK) return rs;
+                unsigned short* elems = (unsigned short*)ctx->aux;
+                unsigned int* offs = (unsigned int*)((char*)ctx->aux + elem_bytes);
+                unsigned int* valid = offs + (size_t)(buckets + 1) * chunks;
+                const size_t lds1 = (size_t)slots * 8 + (size_t)(2 * kBucketsMax + 2) * sizeof(unsigned int) + (size_t)chunk * 2;
+                hipLaunchKernelGGL(count_bucket_scatter_kernel, dim3(chunks), dim3(kThreads), lds1, ctx->stream, d_labels, st,
+                                   k, R, buckets, chunk, slots, elems, offs, valid);
+                int copies = 1;
+                while (copies < kThreads / 64 && (size_t)2 * copies * bin_bytes <= (size_t)kBinCopiesBytes) copies *= 2;
+                const size_t lds2 = (size_t)copies * bin_bytes + (size_t)(2 * kThreads + 1) * sizeof(unsigned int);
+                hipLaunchKernelGGL(count_bucket_bin_kernel, dim3(buckets), dim3(kThreads), lds2, ctx->stream,
+                                   (const unsigned short*)elems, (const unsigned int*)offs, chunks, chunk, k, R, copies,
+                                   (unsigned long long*)d_counts, (const unsigned int*)valid, (unsigned long long*)d_pairs);
+                MSM_CHECK_LAUNCH(ctx);
+                return MSM_OK;
+            }
+        }
+    }
     MSM_HIP(ctx, hipMemsetAsync(d_counts, 0, (size_t)k * k * sizeof(out_t), ctx->stream));
     if (d_pairs) MSM_HIP(ctx, hipMemsetAsync(d_pairs, 0, sizeof(int64_t), ctx->stream));
     if (st.total_pairs == 0) return MSM_OK;

@@ -76,6 +76,42 @@ def test_counts_vs_oracle_sizes(engine, n, k, lag):
     np.testing.assert_array_equal(v.to_host(), cport.state_counts(lab_h, k))
 
 
+@pytest.mark.parametrize("kind", ["constant", "runs", "two_states", "random"])
+@pytest.mark.parametrize("n,k,lag", [(300_000, 257, 7), (2_000_000, 1200, 3), (70_000, 256, 1)])
+def test_bucket_path_label_statistics(engine, kind, n, k, lag):
+    """The two-pass bucket path (pairs >= bins): rows per bucket that do not divide k, several bin copies or one,
+    long dwells (run combining) and labels that all land in one bucket."""
+    rng = np.random.default_rng(k + lag)
+    if kind == "constant":
+        lab_h = np.full(n, k - 1, np.int32)
+    elif kind == "runs":
+        lab_h = np.repeat(rng.integers(0, k, n // 37 + 1), 37)[:n].astype(np.int32)
+    elif kind == "two_states":
+        lab_h = (rng.integers(0, 2, n) * (k - 1)).astype(np.int32)
+    else:
+        lab_h = rng.integers(0, k, n).astype(np.int32)
+    lab_h[::4099] = -1
+    lab_h[3::7001] = k
+    want, pw = cport.count_transitions(lab_h, k, lag)
+    c, p = engine.count_transitions(engine.to_device(lab_h), k, lag)
+    np.testing.assert_array_equal(c.to_host(), want)
+    assert int(p.to_host()[0]) == pw
+
+
+def test_bucket_path_many_chunks(engine, monkeypatch):
+    """More first-pass workgroups than one tile of the second pass gathers (1024): forced with tiny chunks."""
+    monkeypatch.setenv("MSM_COUNTS_CHUNK", "64")
+    n, k = 100_000, 120
+    lab_h = _gen.markov_labels(n, k, 3)
+    segs = [(0, 30_001), (30_001, 30_002), (30_010, n)]
+    s, e = _bounds(segs)
+    for lag, stride in [(9, 1), (2, 3)]:
+        want, pw = cport.count_transitions(lab_h, k, lag, segments=segs, stride=stride)
+        c, p = engine.count_transitions(engine.to_device(lab_h), k, lag, starts=s, stops=e, stride=stride)
+        np.testing.assert_array_equal(c.to_host(), want)
+        assert int(p.to_host()[0]) == pw
+
+
 def test_many_segments_and_ragged(engine):
     rng = np.random.default_rng(0)
     n, k = 250_000, 64
