@@ -438,6 +438,17 @@ msm_status msm_kmeans_accumulate_delta(msm_ctx* ctx, const void* d_x, msm_dtype 
                                        int64_t ld, const double* d_centers, int k, const double* d_mean,
                                        const double* d_std, const void* d_image, const double* d_state,
                                        int32_t* d_prev_labels, int64_t* d_sums, int64_t* d_counts);
+/* One whole Lloyd iteration: the accumulate pass above (incremental when d_prev_labels is given, which then needs
+ * persistent d_sums / d_counts) followed by msm_kmeans_update(clear = 0) on d_centers / d_state -- in ONE launch where
+ * the filter kernel runs: the workgroup that finishes last closes the iteration, with the bits of the separate update
+ * kernel.  For a single shard; with several shards the sums are reduced between the two halves
+ * (msm_kmeans_accumulate_delta, msm_allreduce_i64_from, msm_kmeans_update).
+ * Reference: one iteration of deeptime KMeans.fit / sklearn KMeans behind cluster_microstates
+ * (S/markov_state_model/clustering.py:322-361) and _KMeansDiscretizer.fit (S/analysis/discretize.py:458-469). */
+msm_status msm_kmeans_lloyd_pass(msm_ctx* ctx, const void* d_x, msm_dtype dtype, int64_t n, int d, int64_t ld,
+                                 double* d_centers, int k, const double* d_mean, const double* d_std,
+                                 const void* d_image, double* d_state, int32_t* d_prev_labels, int64_t* d_sums,
+                                 int64_t* d_counts);
 msm_status msm_kmeans_filter_scanned(msm_ctx* ctx, uint64_t* h_out, int reset);
 /* Hardware rule the filter's certificate rests on (kmeans_filter.h, step 1): n_tiles independent
  * v_mfma_f32_16x16x32_bf16 instructions, D = A B + C with A [16][32], B [32][16] bf16 (row major, raw 16-bit

@@ -99,6 +99,7 @@ _PROTOTYPES: dict[str, tuple] = {
     "msm_kmeans_pack": (_i32, [_vp, _vp, _i32, _i64, _i32, _i64, _vp, _vp, _vp]),
     "msm_kmeans_assign_packed": (_i32, [_vp, _vp, _i32, _i64, _i32, _i64, _vp, _i32, _vp, _vp, _vp, _vp, _vp]),
     "msm_kmeans_accumulate_packed": (_i32, [_vp, _vp, _i32, _i64, _i32, _i64, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "msm_kmeans_lloyd_pass": (_i32, [_vp, _vp, _i32, _i64, _i32, _i64, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "msm_kmeans_accumulate_delta": (_i32, [_vp, _vp, _i32, _i64, _i32, _i64, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp,
                                            _vp]),
     "msm_kmeans_filter_scanned": (_i32, [_vp, C.POINTER(C.c_uint64), _i32]),

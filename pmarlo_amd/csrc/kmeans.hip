@@ -152,15 +152,28 @@ __global__ __launch_bounds__(1024) void kmeans_update_kernel(unsigned long long*
     if (st->done != 0.0) return;
     const double inv_scale = st->inv_scale;
     double acc = 0.0;
-    for (int i = threadIdx.x; i < k * d; i += blockDim.x) {
-        const int j = i / d;
-        const long long cnt = (long long)counts[j];
-        if (cnt > 0) {
-            const double c_new = (double)(long long)sums[i] * inv_scale / (double)cnt;
-            const double dlt = c_new - centers[i];
-            acc = fma(dlt, dlt, acc);
-            centers[i] = c_new;
+    constexpr int CH = 4;       // elements in flight per thread: the loads of a chunk before the arithmetic of any
+    for (int i0 = threadIdx.x; i0 < k * d; i0 += 1024 * CH) {
+        long long cnt[CH], sm[CH];
+        double old[CH];
+#pragma unroll
+        for (int c = 0; c < CH; ++c) {
+            const int i = i0 + c * 1024;
+            cnt[c] = 0;
+            if (i < k * d) {
+                cnt[c] = (long long)counts[i / d];
+                sm[c] = (long long)sums[i];
+                old[c] = centers[i];
+            }
         }
+#pragma unroll
+        for (int c = 0; c < CH; ++c)
+            if (cnt[c] > 0) {
+                const double c_new = (double)sm[c] * inv_scale / (double)cnt[c];
+                const double dlt = c_new - old[c];
+                acc = fma(dlt, dlt, acc);
+                centers[i0 + c * 1024] = c_new;
+            }
     }
     for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
@@ -918,8 +931,8 @@ msm_status filter_stats_buffer(msm_ctx* ctx, unsigned long long** out) {
     static_assert(sizeof(unsigned long long) == 8, "");
     if (!ctx->km_stats) {
         if (ctx->capturing) { *out = nullptr; return MSM_OK; }
-        MSM_HIP(ctx, hipMalloc(&ctx->km_stats, 8));
-        MSM_HIP(ctx, hipMemsetAsync(ctx->km_stats, 0, 8, ctx->stream));
+        MSM_HIP(ctx, hipMalloc(&ctx->km_stats, 16));       // [frames scanned u64 | arrival ticket of the fused update u32 | pad]
+        MSM_HIP(ctx, hipMemsetAsync(ctx->km_stats, 0, 16, ctx->stream));
     }
     *out = (unsigned long long*)ctx->km_stats;
     return MSM_OK;
@@ -928,7 +941,7 @@ msm_status filter_stats_buffer(msm_ctx* ctx, unsigned long long** out) {
 template <typename T, int NM, bool ACCUM>
 msm_status launch_filter_nm(msm_ctx* ctx, const T* x, int64_t n, int d, int64_t ld, const double* centers, int k,
                             const double* mean, const double* stdv, const uint4* image, int32_t* labels, double* mindist,
-                            const FitState* st, unsigned long long* sums, unsigned long long* counts) {
+                            const FitState* st, unsigned long long* sums, unsigned long long* counts, double* upd_centers) {
     constexpr int NF = 4;
     const size_t lds = filter_lds_bytes(k, d, ACCUM);
     // (the centre tables are built by every workgroup of the kernel for itself: no staging launch)
@@ -943,7 +956,8 @@ msm_status launch_filter_nm(msm_ctx* ctx, const T* x, int64_t n, int d, int64_t 
     if (lds > 48 * 1024)
         MSM_HIP(ctx, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * kWaves), lds, ctx->stream, x, n, d, ld, k, mean, stdv, image, centers,
-                       labels, mindist, st, sums, counts, stats);
+                       labels, mindist, st, sums, counts, stats, stats ? upd_centers : nullptr,
+                       stats ? (unsigned int*)(stats + 1) : nullptr);
     MSM_CHECK_LAUNCH(ctx);
     return MSM_OK;
 }
@@ -951,11 +965,12 @@ msm_status launch_filter_nm(msm_ctx* ctx, const T* x, int64_t n, int d, int64_t 
 template <typename T, bool ACCUM>
 msm_status launch_filter(msm_ctx* ctx, const T* x, int64_t n, int d, int64_t ld, const double* centers, int k,
                          const double* mean, const double* stdv, const uint4* image, int32_t* labels, double* mindist,
-                         const FitState* st, unsigned long long* sums, unsigned long long* counts) {
+                         const FitState* st, unsigned long long* sums, unsigned long long* counts, double* upd_centers) {
     if (filter_nm(d) == 1)
         return launch_filter_nm<T, 1, ACCUM>(ctx, x, n, d, ld, centers, k, mean, stdv, image, labels, mindist, st, sums,
-                                             counts);
-    return launch_filter_nm<T, 2, ACCUM>(ctx, x, n, d, ld, centers, k, mean, stdv, image, labels, mindist, st, sums, counts);
+                                             counts, upd_centers);
+    return launch_filter_nm<T, 2, ACCUM>(ctx, x, n, d, ld, centers, k, mean, stdv, image, labels, mindist, st, sums, counts,
+                                         upd_centers);
 }
 
 bool filter_fits(int k, int d, bool accum) { return filter_enabled() && d <= kFilterMaxD && filter_lds_bytes(k, d, accum) != 0; }
@@ -964,7 +979,12 @@ bool filter_fits(int k, int d, bool accum) { return filter_enabled() && d <= kFi
 template <typename T, bool ACCUM>
 msm_status dispatch_mfma(msm_ctx* ctx, const T* x, int64_t n, int d, int64_t ld, const double* centers, int k,
                          const double* mean, const double* stdv, int32_t* labels, double* mindist, const FitState* st,
-                         unsigned long long* sums, unsigned long long* counts, const void* image = nullptr) {
+                         unsigned long long* sums, unsigned long long* counts, const void* image = nullptr,
+                         double* upd_centers = nullptr, bool* folded = nullptr) {
+    // upd_centers: close the Lloyd iteration inside the accumulate launch (its last workgroup); *folded tells the caller
+    // whether that happened (filter path, small table, not under a capture without the ticket word) or the separate update
+    // launch is still due
+    if (folded) *folded = false;
     if (filter_fits(k, d, ACCUM)) {
         if (!image) {
             msm_status rs = msm_reserve_km_image(ctx, filter_image_bytes(n, d));
@@ -973,8 +993,10 @@ msm_status dispatch_mfma(msm_ctx* ctx, const T* x, int64_t n, int d, int64_t ld,
             if (rs != MSM_OK) return rs;
             image = ctx->km_image;
         }
+        if (upd_centers && !(ACCUM && (int64_t)k * d <= kUpdateWide && (ctx->km_stats || !ctx->capturing))) upd_centers = nullptr;
+        if (folded) *folded = upd_centers != nullptr;
         return launch_filter<T, ACCUM>(ctx, x, n, d, ld, centers, k, mean, stdv, (const uint4*)image, labels, mindist, st,
-                                       sums, counts);
+                                       sums, counts, upd_centers);
     }
 #define MSM_MFMA_CASE(KSV) \
     if (d <= 4 * KSV)      \
@@ -1124,7 +1146,9 @@ msm_status msm_kmeans_fit_begin(msm_ctx* ctx, const void* d_x, msm_dtype dtype, 
 static msm_status kmeans_accumulate_impl(msm_ctx* ctx, const void* d_x, msm_dtype dtype, int64_t n, int d, int64_t ld,
                                          const double* d_centers, int k, const double* d_mean, const double* d_std,
                                          const void* d_image, const double* d_state, int64_t* d_sums, int64_t* d_counts,
-                                         int32_t* d_prev_labels = nullptr) {
+                                         int32_t* d_prev_labels = nullptr, double* d_update_centers = nullptr,
+                                         bool* folded = nullptr) {
+    if (folded) *folded = false;
     if (!ctx) return MSM_ERR_INVALID;
     MSM_REQUIRE(ctx, n >= 0 && d >= 1 && k >= 1 && ld >= d, "msm_kmeans_accumulate: bad shape");
     MSM_REQUIRE(ctx, (d_mean == nullptr) == (d_std == nullptr), "msm_kmeans_accumulate: mean/std must come together");
@@ -1134,10 +1158,23 @@ static msm_status kmeans_accumulate_impl(msm_ctx* ctx, const void* d_x, msm_dtyp
     if (dtype == MSM_F32)
         return dispatch_mfma<float, true>(ctx, (const float*)d_x, n, d, ld, d_centers, k, d_mean, d_std, d_prev_labels,
                                           nullptr, (const FitState*)d_state, (unsigned long long*)d_sums,
-                                          (unsigned long long*)d_counts, d_image);
+                                          (unsigned long long*)d_counts, d_image, d_update_centers, folded);
     return dispatch_mfma<double, true>(ctx, (const double*)d_x, n, d, ld, d_centers, k, d_mean, d_std, d_prev_labels,
                                        nullptr, (const FitState*)d_state, (unsigned long long*)d_sums,
-                                       (unsigned long long*)d_counts, d_image);
+                                       (unsigned long long*)d_counts, d_image, d_update_centers, folded);
+}
+
+// One Lloyd iteration: member sums of the frames under `d_centers` (following the frames that change centre when
+// d_prev_labels is given), then centres <- sums / counts, shift and convergence flag -- in ONE launch where the filter
+// kernel runs (its last workgroup closes the iteration), else msm_kmeans_accumulate* + msm_kmeans_update.
+msm_status msm_kmeans_lloyd_pass(msm_ctx* ctx, const void* d_x, msm_dtype dtype, int64_t n, int d, int64_t ld,
+                                 double* d_centers, int k, const double* d_mean, const double* d_std, const void* d_image,
+                                 double* d_state, int32_t* d_prev_labels, int64_t* d_sums, int64_t* d_counts) {
+    bool folded = false;
+    msm_status rs = kmeans_accumulate_impl(ctx, d_x, dtype, n, d, ld, d_centers, k, d_mean, d_std, d_image, d_state, d_sums,
+                                           d_counts, d_prev_labels, d_centers, &folded);
+    if (rs != MSM_OK || folded) return rs;
+    return msm_kmeans_update(ctx, d_sums, d_counts, k, d, d_centers, d_state, 0);
 }
 
 msm_status msm_kmeans_accumulate_delta(msm_ctx* ctx, const void* d_x, msm_dtype dtype, int64_t n, int d, int64_t ld,
@@ -1219,10 +1256,7 @@ msm_status msm_kmeans_fit(msm_ctx* ctx, const void* d_x, msm_dtype dtype, int64_
         image = ctx->km_image;
     }
     for (int it = 0; it < max_iter; ++it) {
-        rs = kmeans_accumulate_impl(ctx, d_x, dtype, n, d, ld, d_centers, k, d_mean, d_std, image, d_state, sums, counts,
-                                    prev);
-        if (rs != MSM_OK) return rs;
-        rs = msm_kmeans_update(ctx, sums, counts, k, d, d_centers, d_state, 0);
+        rs = msm_kmeans_lloyd_pass(ctx, d_x, dtype, n, d, ld, d_centers, k, d_mean, d_std, image, d_state, prev, sums, counts);
         if (rs != MSM_OK) return rs;
     }
     return MSM_OK;

@@ -452,6 +452,58 @@ __device__ __forceinline__ void filter_load_frame(const T* __restrict__ x, int64
 
 // ---------------------------------------------------------------------------------------------------------
 // LDS of the main kernel: img | tab | hs | lsum [k][d], lcnt [k] u64 (ACCUM)
+// centres <- sums / counts, shift2, n_iter, done: what kmeans_update_kernel (kmeans.hip) does, by one workgroup of MT
+// threads, with the additions of shift2 in the order of that kernel's 1024 threads (virtual thread v takes the
+// elements v, v + 1024, ...; 64 consecutive virtual threads add up by the same shuffles; the sixteen partial sums in
+// order), so the two ways of closing an iteration give the same bits.  sums / counts were last written by other
+// workgroups' atomics: read them with device-scope loads.
+template <int MT>
+__device__ __forceinline__ void filter_close_iteration(const unsigned long long* sums, const unsigned long long* counts, int k,
+                                                       int d, double* centers, FitState* st) {
+    __shared__ double red[16];
+    const int tid = threadIdx.x;
+    const double inv_scale = st->inv_scale;
+    for (int v0 = 0; v0 < 1024; v0 += MT) {
+        const int v = v0 + tid;
+        if (v < 1024) {                 // whole waves: MT and 1024 are multiples of 64
+            double acc = 0.0;
+            constexpr int CH = 4;       // elements in flight per thread: the loads of a chunk before the arithmetic of any
+            for (int i0 = v; i0 < k * d; i0 += 1024 * CH) {
+                long long cnt[CH], sm[CH];
+                double old[CH];
+#pragma unroll
+                for (int c = 0; c < CH; ++c) {
+                    const int i = i0 + c * 1024;
+                    cnt[c] = 0;
+                    if (i < k * d) {
+                        cnt[c] = (long long)__hip_atomic_load(&counts[i / d], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        sm[c] = (long long)__hip_atomic_load(&sums[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        old[c] = centers[i];
+                    }
+                }
+#pragma unroll
+                for (int c = 0; c < CH; ++c)
+                    if (cnt[c] > 0) {
+                        const double c_new = (double)sm[c] * inv_scale / (double)cnt[c];
+                        const double dlt = c_new - old[c];
+                        acc = fma(dlt, dlt, acc);
+                        centers[i0 + c * 1024] = c_new;
+                    }
+            }
+            for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
+            if ((v & 63) == 0) red[v >> 6] = acc;
+        }
+    }
+    __syncthreads();
+    if (tid == 0) {
+        double t = 0.0;
+        for (int i = 0; i < 16; ++i) t += red[i];
+        st->shift2 = t;
+        st->n_iter += 1.0;
+        if (t <= st->tol2) st->done = 1.0;
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------------
 template <typename T, int NM, int NF, bool ACCUM, bool WHITEN>
 __global__ __launch_bounds__(64 * filter_waves(NM)) void kmeans_filter_kernel(
@@ -459,7 +511,8 @@ __global__ __launch_bounds__(64 * filter_waves(NM)) void kmeans_filter_kernel(
     const double* __restrict__ stdv, const uint4* __restrict__ image, const double* __restrict__ centers,
     int32_t* __restrict__ labels,
     double* __restrict__ mindist, const FitState* __restrict__ st, unsigned long long* __restrict__ sums,
-    unsigned long long* __restrict__ counts, unsigned long long* __restrict__ n_scanned) {
+    unsigned long long* __restrict__ counts, unsigned long long* __restrict__ n_scanned, double* upd_centers,
+    unsigned int* __restrict__ ticket) {
     using S = FilterShape<NM>;
     constexpr int kFilterWaves = filter_waves(NM);
     constexpr int kMT = 64 * kFilterWaves, DP = S::DP, RF = S::RF, RQ = filter_rowq(NM);
@@ -920,6 +973,26 @@ __global__ __launch_bounds__(64 * filter_waves(NM)) void kmeans_filter_kernel(
             if (lsum[i]) atomicAdd(&sums[i], lsum[i]);
         for (int i = tid; i < k; i += kMT)
             if (lcnt[i]) atomicAdd(&counts[i], lcnt[i]);
+        // The workgroup that finishes LAST closes the Lloyd iteration (centres <- sums / counts, shift, convergence flag)
+        // instead of a one-workgroup launch of its own after this one: every other workgroup has then added its member
+        // sums and read the old centres for the last time.
+        if (upd_centers) {
+            // Ordering without a device-wide fence (__threadfence() = buffer_wbl2: a write-back of the XCD's whole L2 by
+            // every workgroup, +45 us per launch, measured): the member sums travel as atomics, which are resolved at
+            // the device's coherence point, and every wave waits for the acknowledgement of its own (vmcnt) before the
+            // workgroup takes its ticket; the closing workgroup reads them with device-scope loads, and nothing in
+            // this launch has read sums / counts before, so no cache holds an older copy.
+            __shared__ int is_last;
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (tid == 0) {
+                const unsigned t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                is_last = t == gridDim.x - 1;
+                if (is_last) __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
+            }
+            __syncthreads();
+            if (is_last) filter_close_iteration<kMT>(sums, counts, k, d, upd_centers, const_cast<FitState*>(st));
+        }
     }
     KSTAMP_FLUSH
 }

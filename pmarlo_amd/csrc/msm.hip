@@ -1036,9 +1036,27 @@ msm_status msm_spectrum(msm_ctx* ctx, const double* d_T, int64_t t_stride, int l
                 const size_t lds = ((size_t)n_max * (cols | 1) + (size_t)n_max * (p | 1) + (size_t)cols * p) * sizeof(double);
                 MSM_HIP(ctx, hipFuncSetAttribute((const void*)spec_persist_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                                  (int)lds));
-                void* kargs[] = {(void*)&ar, (void*)&pa};
-                hipError_t le = hipLaunchCooperativeKernel((const void*)spec_persist_kernel, dim3((unsigned)(slots * G * 8)),
-                                                           dim3(kSolveThreads), kargs, (unsigned)lds, ctx->stream);
+                // Residency: the barriers need every workgroup of the grid on a CU at once.  The grid is at most one
+                // workgroup per CU (checked here against the occupancy the runtime reports), the stream is in order, and a
+                // barrier that is not met within ~1 s raises the error flag instead of spinning on; a plain launch is
+                // used because rocprofv3 crashes at exit of a process that made a cooperative launch (MSM_SPEC_COOP=1
+                // asks for hipLaunchCooperativeKernel all the same).
+                const unsigned grid = (unsigned)(slots * G * 8);
+                int per_cu = 0;
+                hipError_t le = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)spec_persist_kernel,
+                                                                             kSolveThreads, lds);
+                if (le == hipSuccess && (per_cu < 1 || grid > (unsigned)ctx->n_cu)) le = hipErrorCooperativeLaunchTooLarge;
+                if (le == hipSuccess) {
+                    const char* coop = getenv("MSM_SPEC_COOP");
+                    if (coop && coop[0] == '1') {
+                        void* kargs[] = {(void*)&ar, (void*)&pa};
+                        le = hipLaunchCooperativeKernel((const void*)spec_persist_kernel, dim3(grid), dim3(kSolveThreads), kargs,
+                                                        (unsigned)lds, ctx->stream);
+                    } else {
+                        hipLaunchKernelGGL(spec_persist_kernel, dim3(grid), dim3(kSolveThreads), lds, ctx->stream, ar, pa);
+                        le = hipGetLastError();
+                    }
+                }
                 if (getenv("MSM_SPEC_DEBUG"))
                     fprintf(stderr, "msm_spectrum: persistent launch n=%d p=%d cols=%d G=%d groups=%d lds=%zu -> %s\n", n_max, p,
                             cols, G, groups, lds, hipGetErrorString(le));

@@ -705,6 +705,19 @@ class Engine:
               self.handle)
         return out
 
+    def kmeans_lloyd_pass(self, x: DeviceArray, centers: DeviceArray, state: DeviceArray, sums: DeviceArray,
+                          counts: DeviceArray, *, mean: DeviceArray | None = None, std: DeviceArray | None = None,
+                          image: DeviceArray | None = None, prev_labels: DeviceArray | None = None):
+        """One Lloyd iteration on a single shard: kmeans_accumulate + kmeans_update(clear=False), in one launch where the
+        filter kernel runs (msm_kmeans_lloyd_pass)."""
+        n, d = x.shape
+        k = centers.shape[0]
+        check(lib.msm_kmeans_lloyd_pass(self.handle, x.ptr, _dtype_code(x.dtype), n, d, d, centers.ptr, k,
+                                        mean.ptr if mean is not None else None, std.ptr if std is not None else None,
+                                        image.ptr if image is not None else None, state.ptr,
+                                        prev_labels.ptr if prev_labels is not None else None, sums.ptr, counts.ptr),
+              self.handle)
+
     def kmeans_update(self, sums: DeviceArray, counts: DeviceArray, centers: DeviceArray, state: DeviceArray,
                       clear: bool = True):
         k, d = centers.shape

@@ -467,14 +467,19 @@ class ShardedMSM:
             if self.time_accum:
                 e0, e1 = eng.event(), eng.event()
                 e0.record()
-            eng.kmeans_accumulate(self.Y, b["centers"], b["fit_state"], acc_sums, acc_counts,
-                                  image=self.km_image, prev_labels=self.labels)
+            if not multi:
+                # one shard: the accumulate launch closes the iteration itself (its last workgroup)
+                eng.kmeans_lloyd_pass(self.Y, b["centers"], b["fit_state"], acc_sums, acc_counts,
+                                      image=self.km_image, prev_labels=self.labels)
+            else:
+                eng.kmeans_accumulate(self.Y, b["centers"], b["fit_state"], acc_sums, acc_counts,
+                                      image=self.km_image, prev_labels=self.labels)
             if self.time_accum:
                 e1.record()
                 self.accum_events.append((e0, e1))
             if multi:
                 comm.allreduce_sum_from("km_acc", self.km_local)     # out of place: no copy in front of the collective
-            eng.kmeans_update(self.km_sums, self.km_counts, b["centers"], b["fit_state"], clear=False)
+                eng.kmeans_update(self.km_sums, self.km_counts, b["centers"], b["fit_state"], clear=False)
         eng.kmeans_assign(self.Y, b["centers"], labels=self.labels, image=self.km_image)
         self._stamp("kmeans")
         # 5. lag-tau counts (a whole lag scan in one pass and ONE collective) + row-normalised transition matrix

@@ -164,6 +164,10 @@ class HostEngine:
         np.subtract.at(counts.a, old[had], 1)
         old[...] = lab
 
+    def kmeans_lloyd_pass(self, x, centers, state, sums, counts, prev_labels=None, **kw):
+        self.kmeans_accumulate(x, centers, state, sums, counts, prev_labels=prev_labels, **kw)
+        self.kmeans_update(sums, counts, centers, state, clear=False)
+
     def kmeans_update(self, sums, counts, centers, state, clear=True):
         if state.a[5] != 0.0:
             return

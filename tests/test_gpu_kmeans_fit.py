@@ -198,3 +198,32 @@ def test_incremental_member_sums_equal_full_passes(engine, d, k):
         moved.append(int((before != lab).sum()))
         engine.kmeans_update(sums_i, counts_i, centers, state, clear=False)
     assert moved[0] == n and moved[-1] < moved[1] < n          # fewer and fewer frames move
+
+
+@pytest.mark.parametrize("d,k,tol2", [(10, 300, 0.0), (10, 500, 1e-3), (6, 40, 1e-2), (24, 60, 0.0)])
+def test_fused_lloyd_pass_equals_accumulate_then_update(engine, d, k, tol2):
+    """msm_kmeans_lloyd_pass (the last workgroup of the accumulate launch closes the iteration; shapes outside the filter
+    kernel fall back to two launches) against msm_kmeans_accumulate_delta + msm_kmeans_update: centres and the whole
+    fit state (shift2, n_iter, done) bit for bit, also across the iteration where the tolerance stops the run."""
+    n = 80_000
+    X = _gen.correlated_series(n, d, seed=9).astype(np.float64)
+    xd = engine.to_device(X)
+    runs = []
+    for fused in (False, True):
+        centers, state = engine.kmeans_fit_begin(xd, k, seed=3, n_total=n, tol2=tol2)
+        sums, counts = engine.zeros((k * d,), np.int64), engine.zeros((k,), np.int64)
+        prev = engine.empty((n,), np.int32).fill_bytes_(0xFF)
+        trace = []
+        for _ in range(12):
+            if fused:
+                engine.kmeans_lloyd_pass(xd, centers, state, sums, counts, prev_labels=prev)
+            else:
+                engine.kmeans_accumulate(xd, centers, state, sums, counts, prev_labels=prev)
+                engine.kmeans_update(sums, counts, centers, state, clear=False)
+            trace.append((centers.to_host().copy(), state.to_host().copy()))
+        runs.append(trace)
+    for (c0, s0), (c1, s1) in zip(*runs):
+        np.testing.assert_array_equal(c0, c1)
+        np.testing.assert_array_equal(s0, s1)
+    if tol2 > 0.0:
+        assert runs[1][-1][1][5] == 1.0 or runs[1][-1][1][3] > tol2       # done flag set once the shift fell below tol2
