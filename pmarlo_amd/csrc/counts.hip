@@ -153,8 +153,8 @@ __device__ __forceinline__ unsigned block_excl_scan_u32(unsigned v, unsigned* to
     return wave_tot[wave] + inc - v;
 }
 
-// Pass 1.  grid = chunks.  elems: [chunks][chunk] uint16, offs: [buckets + 1][chunks] uint32 (transposed: pass 2 reads a
-// bucket's offsets of all chunks as one contiguous row).  slots: power of two >= 2 chunk.
+// Pass 1.  grid = chunks.  elems: [chunks][chunk] uint16, offs: [chunks][buckets + 1] uint32 (a coalesced row per chunk;
+// the transposed layout cost a 32-byte write transaction per 4-byte offset).  slots: power of two >= 2 chunk.
 __global__ __launch_bounds__(kThreads) void count_bucket_scatter_kernel(const int32_t* __restrict__ labels, SegTab st, int k,
                                                                        int R, int buckets, int chunk, int slots,
                                                                        unsigned short* __restrict__ elems,
@@ -167,7 +167,6 @@ __global__ __launch_bounds__(kThreads) void count_bucket_scatter_kernel(const in
     unsigned int* start = hist + kBucketsMax;                                        // [kBucketsMax + 1]
     unsigned short* out = reinterpret_cast<unsigned short*>(start + kBucketsMax + 1 + 1);   // [chunk] elements by bucket
     const int tid = threadIdx.x, lane = tid & 63;
-    const int chunks = gridDim.x;
     for (int i = tid; i < slots; i += kThreads) { tkey[i] = kSlotEmpty; tcnt[i] = 0; }
     if (tid < kBucketsMax) hist[tid] = 0;
     __syncthreads();
@@ -231,14 +230,14 @@ __global__ __launch_bounds__(kThreads) void count_bucket_scatter_kernel(const in
     unsigned int* dst = reinterpret_cast<unsigned int*>(elems + (size_t)blockIdx.x * chunk);     // chunk is even
     const unsigned int* src = reinterpret_cast<const unsigned int*>(out);
     for (int i = tid; i < (int)((total + 1) >> 1); i += kThreads) dst[i] = src[i];
-    if (tid <= buckets) offs[(size_t)tid * chunks + blockIdx.x] = start[tid];
+    if (tid <= buckets) offs[(size_t)blockIdx.x * (buckets + 1) + tid] = start[tid];     // one coalesced row per chunk
     if (tid == 0) valid_out[blockIdx.x] = n_valid;
 }
 
-// Pass 2.  grid = buckets; workgroup b owns the rows [b R, b R + R) of the matrix.
+// Pass 2.  grid = buckets rounded up to a multiple of 8; workgroup b owns the rows [b R, b R + R) of the matrix.
 __global__ __launch_bounds__(kThreads) void count_bucket_bin_kernel(const unsigned short* __restrict__ elems,
                                                                    const unsigned int* __restrict__ offs, int chunks,
-                                                                   int chunk, int k, int R, int copies,
+                                                                   int chunk, int k, int R, int n_buckets, int copies,
                                                                    unsigned long long* __restrict__ counts,
                                                                    const unsigned int* __restrict__ valid,
                                                                    unsigned long long* __restrict__ pairs_out) {
@@ -248,15 +247,20 @@ __global__ __launch_bounds__(kThreads) void count_bucket_bin_kernel(const unsign
     unsigned int* pref = bins + (size_t)copies * nb;                       // [kThreads + 1] group prefix of this tile
     unsigned int* base = pref + kThreads + 1;                              // [kThreads] first element of the group in `elems`
     const int tid = threadIdx.x;
-    const int b = blockIdx.x;
+    // Workgroup ids that differ by multiples of 8 share an XCD (and its L2): give each XCD a CONTIGUOUS range of buckets.
+    // The groups of neighbouring buckets lie next to each other in a chunk's element row and are shorter than a cache
+    // line, so a line is then fetched from HBM by one XCD instead of by up to four (10.5 -> read-side MB in r03_pmc_hbm.md).
+    const int per_xcd = (n_buckets + 7) / 8;       // grid = 8 per_xcd
+    const int b = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+    if (b >= n_buckets) return;          // (whole workgroup; the ids of a short last range)
     for (int i = tid; i < copies * nb; i += kThreads) bins[i] = 0;
     unsigned int* my_bins = bins + (size_t)((tid >> 6) & (copies - 1)) * nb;   // copies is a power of two
     for (int w0 = 0; w0 < chunks; w0 += kThreads) {
         const int w = w0 + tid;
         unsigned s = 0, len = 0;
         if (w < chunks) {
-            s = offs[(size_t)b * chunks + w];
-            len = offs[(size_t)(b + 1) * chunks + w] - s;
+            s = offs[(size_t)w * (n_buckets + 1) + b];
+            len = offs[(size_t)w * (n_buckets + 1) + b + 1] - s;
         }
         unsigned total;
         const unsigned ex = block_excl_scan_u32(len, &total);      // (its barriers also cover the zeroing above)
@@ -436,8 +440,8 @@ msm_status launch_counts(msm_ctx* ctx, const int32_t* d_labels, const double* d_
                 int copies = 1;
                 while (copies < kThreads / 64 && (size_t)2 * copies * bin_bytes <= (size_t)kBinCopiesBytes) copies *= 2;
                 const size_t lds2 = (size_t)copies * bin_bytes + (size_t)(2 * kThreads + 1) * sizeof(unsigned int);
-                hipLaunchKernelGGL(count_bucket_bin_kernel, dim3(buckets), dim3(kThreads), lds2, ctx->stream,
-                                   (const unsigned short*)elems, (const unsigned int*)offs, chunks, chunk, k, R, copies,
+                hipLaunchKernelGGL(count_bucket_bin_kernel, dim3(8 * ((buckets + 7) / 8)), dim3(kThreads), lds2, ctx->stream,
+                                   (const unsigned short*)elems, (const unsigned int*)offs, chunks, chunk, k, R, buckets, copies,
                                    (unsigned long long*)d_counts, (const unsigned int*)valid, (unsigned long long*)d_pairs);
                 MSM_CHECK_LAUNCH(ctx);
                 return MSM_OK;
