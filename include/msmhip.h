@@ -521,6 +521,18 @@ msm_status msm_spectrum(msm_ctx* ctx, const double* d_T, int64_t t_stride, int l
                         void* d_workspace, double* d_ritz, double* d_pi, int64_t pi_stride,
                         double* d_change, int32_t* d_status, int n_its, const double* d_lags,
                         double* d_its_eig, double* d_its_ts, double freeze_tol, double* d_vecs, int n_vecs);
+/* d_out <- T^(2^n_squarings) for the same batch layout (fp64 matrix cores; entries outside the d_n[b] x d_n[b] block
+ * zero).  d_scratch: a second buffer of the batch's size (may be NULL for one squaring).  msm_spectrum_powered is
+ * msm_spectrum with the ITERATIONS run on such a power d_T_power (same invariant subspaces, the convergence ratio
+ * raised to that power: a quarter of the iterations with T^4); the Rayleigh-Ritz values, residuals, pi, implied
+ * timescales and vectors are those of d_T itself.  Same reference operators as msm_spectrum. */
+msm_status msm_matrix_power(msm_ctx* ctx, const double* d_T, int64_t t_stride, int ld, const int32_t* d_n, int n_max,
+                            int batch, int n_squarings, double* d_scratch, double* d_out);
+msm_status msm_spectrum_powered(msm_ctx* ctx, const double* d_T, const double* d_T_power, int64_t t_stride, int ld,
+                                const int32_t* d_n, int n_max, int batch, int p, int n_iter, int init, uint64_t seed,
+                                int n_watch, void* d_workspace, double* d_ritz, double* d_pi, int64_t pi_stride,
+                                double* d_change, int32_t* d_status, int n_its, const double* d_lags,
+                                double* d_its_eig, double* d_its_ts, double freeze_tol, double* d_vecs, int n_vecs);
 
 /* Reversible maximum-likelihood estimate: deeptime's MaximumLikelihoodMSM(reversible=True) as
  * called by _fit_msm_deeptime (S/markov_state_model/_msm_utils.py:210-262) and the lag selector

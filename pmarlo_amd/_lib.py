@@ -112,6 +112,9 @@ _PROTOTYPES: dict[str, tuple] = {
     "msm_spectrum_workspace_bytes": (_sz, [_i32, _i32, _i32]),
     "msm_spectrum": (_i32, [_vp, _vp, _i64, _i32, _vp, _i32, _i32, _i32, _i32, _i32, C.c_uint64, _i32, _vp, _vp, _vp,
                             _i64, _vp, _vp, _i32, _vp, _vp, _vp, _f64, _vp, _i32]),
+    "msm_matrix_power": (_i32, [_vp, _vp, _i64, _i32, _vp, _i32, _i32, _i32, _vp, _vp]),
+    "msm_spectrum_powered": (_i32, [_vp, _vp, _vp, _i64, _i32, _vp, _i32, _i32, _i32, _i32, _i32, C.c_uint64, _i32, _vp, _vp,
+                                    _vp, _i64, _vp, _vp, _i32, _vp, _vp, _vp, _f64, _vp, _i32]),
     "msm_sample_transition_matrices": (_i32, [_vp, _vp, _i32, _i32, _vp, _vp, _f64, C.c_uint64, _i32, _i32, _vp, _i64,
                                               _i32]),
     "msm_reversible_mle": (_i32, [_vp, _vp, _i32, _i32, _f64, _i32, _vp, _i32, _vp, _vp, _vp]),

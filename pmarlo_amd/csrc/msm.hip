@@ -353,26 +353,50 @@ __device__ unsigned long long g_spec_stamps[8];
 // mode bits
 constexpr int kStepInit = 1;     // seeded basis -> orthonormal Z (no partials involved)
 constexpr int kStepOrtho = 2;    // Z <- orth(W)
+constexpr int kStepTwice = 4;    // with kStepOrtho: a second Cholesky-QR pass over Z (the basis the Rayleigh-Ritz step gets
+                                 // when the iterations ran on a power of T: one pass leaves ~cond(W)^2 eps of non-orthogonality)
 constexpr int kStepFinish = 8;   // Rayleigh-Ritz, residuals, pi, implied timescales
 
 // Z = W R^-1 for upper-triangular R (p x p in LDS): R^-1 by one wave (lane = column), then a
 // p-term dot product per element.
+// R^-1 (upper) of the Cholesky factor in LDS by one wave, lane = column (back substitution)
+__device__ __forceinline__ void rinv_wave(const double* R, double* Rinv, int p) {
+    const int c = threadIdx.x & 63;
+    if (c < p) {
+        for (int m = 0; m < p; ++m) Rinv[m * p + c] = 0.0;
+        Rinv[c * p + c] = 1.0 / R[c * p + c];
+        for (int m = c - 1; m >= 0; --m) {
+            double a = 0.0;
+            for (int l = m + 1; l <= c; ++l) a = fma(R[m * p + l], Rinv[l * p + c], a);
+            Rinv[m * p + c] = -a / R[m * p + m];
+        }
+    }
+}
+
+// Cholesky factor R (upper, G = R'R) of the p x p Gram matrix in LDS by one wave, lane = column.  (A version with the
+// columns in registers and readlane broadcasts -- no LDS round trip in the dependent chain, same bits -- measured no
+// faster at p = 12 or 32: the factorisations are not what bounds an orthogonalisation step.)
+__device__ __forceinline__ void chol_wave(const double* G, double* R, int p) {
+    const int j = threadIdx.x & 63;
+    for (int c = 0; c < p; ++c) {
+        double v = 0.0;
+        if (j < p && j >= c) {
+            v = G[c * p + j];
+            for (int m = 0; m < c; ++m) v = fma(-R[m * p + c], R[m * p + j], v);
+        }
+        double diag = __shfl(v, c, 64);
+        if (!(diag > 1e-300)) diag = 1e-300;  // rank-deficient basis: keep going, column dies out
+        const double rcc = sqrt(diag);
+        if (j < p) R[c * p + j] = j > c ? v / rcc : (j == c ? rcc : 0.0);
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
 __device__ __forceinline__ void spec_apply_rinv(SpecShared* sh, int p, const double* __restrict__ W,
                                                 double* __restrict__ Z, int n) {
     const int tid = threadIdx.x;
     double* Rinv = sh->Hw;  // p x p
-    if (tid < 64) {
-        const int c = tid;
-        if (c < p) {
-            for (int m = 0; m < p; ++m) Rinv[m * p + c] = 0.0;
-            Rinv[c * p + c] = 1.0 / sh->R[c * p + c];
-            for (int m = c - 1; m >= 0; --m) {
-                double a = 0.0;
-                for (int l = m + 1; l <= c; ++l) a = fma(sh->R[m * p + l], Rinv[l * p + c], a);
-                Rinv[m * p + c] = -a / sh->R[m * p + m];
-            }
-        }
-    }
+    if (tid < 64) rinv_wave(sh->R, Rinv, p);
     __syncthreads();
     // one row per thread: the whole row of W is requested at once (independent loads), every
     // output is a short FMA chain over registers and the LDS copy of R^-1
@@ -399,22 +423,7 @@ __device__ __forceinline__ void spec_apply_rinv(SpecShared* sh, int p, const dou
 }
 
 __device__ void spec_cholesky(SpecShared* sh, int p) {
-    const int tid = threadIdx.x;
-    if (tid < 64) {
-        const int j = tid;
-        for (int c = 0; c < p; ++c) {
-            double v = 0.0;
-            if (j < p && j >= c) {
-                v = sh->G[c * p + j];
-                for (int m = 0; m < c; ++m) v = fma(-sh->R[m * p + c], sh->R[m * p + j], v);
-            }
-            double diag = __shfl(v, c, 64);
-            if (!(diag > 1e-300)) diag = 1e-300;  // rank-deficient basis: keep going, column dies out
-            const double rcc = sqrt(diag);
-            if (j < p) sh->R[c * p + j] = j > c ? v / rcc : (j == c ? rcc : 0.0);
-            __builtin_amdgcn_wave_barrier();
-        }
-    }
+    if (threadIdx.x < 64) chol_wave(sh->G, sh->R, p);
     __syncthreads();
 }
 
@@ -435,6 +444,7 @@ struct PersistArgs {
     unsigned* counters;    // [groups] arrivals (monotonic)
     int* error;            // [1]
     int G, groups, cols, batch, n_iter;
+    int twice;             // second Cholesky-QR pass over the final basis (iterations on a power of T)
     double* bufA;          // [batch] basis in / out (zw_stride apart)
     double* bufB;          // [batch] the other basis buffer
 };
@@ -468,24 +478,8 @@ struct PersistShared {     // (SpecShared carries 49 KB of Rayleigh-Ritz work sp
     double Rinv[kMaxP * kMaxP];
 };
 
-// Cholesky factor R (upper, G = R'R) of the p x p Gram matrix by one wave, as spec_cholesky
 __device__ __forceinline__ void persist_cholesky(PersistShared* sh, int p) {
-    const int tid = threadIdx.x;
-    if (tid < 64) {
-        const int j = tid;
-        for (int c = 0; c < p; ++c) {
-            double v = 0.0;
-            if (j < p && j >= c) {
-                v = sh->G[c * p + j];
-                for (int m = 0; m < c; ++m) v = fma(-sh->R[m * p + c], sh->R[m * p + j], v);
-            }
-            double diag = __shfl(v, c, 64);
-            if (!(diag > 1e-300)) diag = 1e-300;  // rank-deficient basis: keep going, column dies out
-            const double rcc = sqrt(diag);
-            if (j < p) sh->R[c * p + j] = j > c ? v / rcc : (j == c ? rcc : 0.0);
-            __builtin_amdgcn_wave_barrier();
-        }
-    }
+    if (threadIdx.x < 64) chol_wave(sh->G, sh->R, p);
     __syncthreads();
 }
 
@@ -579,20 +573,19 @@ __global__ __launch_bounds__(kSolveThreads) void spec_persist_kernel(SpecArgs ar
                 sh.G[e] = v;
             }
             __syncthreads();
+          for (int pass = 0; pass < ((pa.twice && it == pa.n_iter - 1) ? 2 : 1); ++pass) {
+            if (pass == 1) {            // Gram matrix of the basis just formed: every member has all of it
+                for (int e = tid; e < p * p; e += kSolveThreads) {
+                    const int a = e / p, c = e - a * p;
+                    double v = 0.0;
+                    for (int i = 0; i < n; ++i) v = fma(Zl[i * ldz + a], Zl[i * ldz + c], v);
+                    sh.G[e] = v;
+                }
+                __syncthreads();
+            }
             persist_cholesky(&sh, p);
             double* Rinv = sh.Rinv;     // R^-1 by one wave (lane = column)
-            if (tid < 64) {
-                const int c = tid;
-                if (c < p) {
-                    for (int m = 0; m < p; ++m) Rinv[m * p + c] = 0.0;
-                    Rinv[c * p + c] = 1.0 / sh.R[c * p + c];
-                    for (int m = c - 1; m >= 0; --m) {
-                        double a = 0.0;
-                        for (int l = m + 1; l <= c; ++l) a = fma(sh.R[m * p + l], Rinv[l * p + c], a);
-                        Rinv[m * p + c] = -a / sh.R[m * p + m];
-                    }
-                }
-            }
+            if (tid < 64) rinv_wave(sh.R, Rinv, p);
             __syncthreads();
             // Z = W R^-1, row by row in place (a thread owns a row: no hazard)
             for (int i = tid; i < n; i += kSolveThreads) {
@@ -606,6 +599,7 @@ __global__ __launch_bounds__(kSolveThreads) void spec_persist_kernel(SpecArgs ar
                 }
             }
             __syncthreads();
+          }
         }
         // the finishing launch expects the orthonormal basis in bufA; the last exchange may still be read from there
         group_barrier(ctr, pa.G, epoch, pa.error);
@@ -615,6 +609,34 @@ __global__ __launch_bounds__(kSolveThreads) void spec_persist_kernel(SpecArgs ar
         }
         group_barrier(ctr, pa.G, epoch, pa.error);   // nobody overwrites Tl / the Gram partials of a matrix still in use
     }
+}
+
+// Z <- Z R^-1 in place (a thread owns a row and has read all of it before it writes)
+__device__ __forceinline__ void spec_apply_rinv_inplace(SpecShared* sh, int p, double* Z, int n) {
+    const int tid = threadIdx.x;
+    double* Rinv = sh->Hw;  // p x p
+    if (tid < 64) rinv_wave(sh->R, Rinv, p);
+    __syncthreads();
+    for (int i = tid; i < n; i += blockDim.x) {
+        double w[kMaxP];
+        const int row = i * p;
+#pragma unroll
+        for (int m = 0; m < kMaxP; ++m) w[m] = m < p ? Z[row + m] : 0.0;
+        double out[kMaxP];
+#pragma unroll
+        for (int c = 0; c < kMaxP; ++c) {
+            double v = 0.0;
+            if (c < p) {
+#pragma unroll
+                for (int m = 0; m <= c; ++m) v = fma(w[m], Rinv[m * p + c], v);
+            }
+            out[c] = v;
+        }
+#pragma unroll
+        for (int c = 0; c < kMaxP; ++c)
+            if (c < p) Z[row + c] = out[c];
+    }
+    __syncthreads();
 }
 
 // Z: current (orthonormal unless between orthogonalisations) basis; Wb: the other buffer.
@@ -708,6 +730,11 @@ __global__ __launch_bounds__(kSolveThreads) void spec_step_kernel(SpecArgs ar, i
         SSTAMP(2);
         spec_apply_rinv(&sh, p, W, Z, n);
         SSTAMP(3);
+        if (mode & kStepTwice) {
+            spec_gram_fast(Z, Z, n, p, sh.G, sh.Hw);
+            spec_cholesky(&sh, p);
+            spec_apply_rinv_inplace(&sh, p, Z, n);
+        }
     }
     if (!(mode & kStepFinish)) {
         if (tid == 0 && sh.status) ar.status[b] = sh.status;
@@ -877,6 +904,60 @@ __global__ __launch_bounds__(kSolveThreads) void spec_step_kernel(SpecArgs ar, i
     if (tid == 0 && ar.persist_error && *ar.persist_error) ar.status[b] = 777;   // a group barrier of the persistent launch timed out
 }
 
+
+// ---- powers of the transition matrices (the iteration operator of msm_spectrum) -----------------------------------
+// C_b = A_b A_b for a batch of packed square matrices of order n_b <= n_fixed (row stride ld), on the fp64 matrix
+// cores: a 64 x 64 tile of C per workgroup, 16 columns of A / rows of A staged through the LDS per trip, wave w owns
+// the rows 16 w .. 16 w + 15 of the tile (four accumulator tiles).  Entries outside the n_b x n_b block are written
+// as zeros.  A subspace iteration with T^4 needs a quarter of the iterations of one with T (its convergence ratio is
+// the fourth power) and the squarings cost 4 n^3 flop per matrix at matrix-core rate: C4's 5000 matrices of order
+// 200 take ~4 ms, a k = 500 matrix 0.1 ms.
+constexpr int kSqTile = 64, kSqK = 16;
+__global__ __launch_bounds__(256) void square_batch_kernel(const double* __restrict__ A, size_t stride, int ld,
+                                                         const int* __restrict__ n_ptr, int n_fixed,
+                                                         double* __restrict__ C) {
+    __shared__ double As[kSqTile][kSqK + 1];
+    __shared__ double Bs[kSqK][kSqTile + 1];
+    const int b = blockIdx.z;
+    const int n = n_ptr ? n_ptr[b] : n_fixed;
+    const int r0 = blockIdx.y * kSqTile, c0 = blockIdx.x * kSqTile;
+    const double* Ab = A + (size_t)b * stride;
+    double* Cb = C + (size_t)b * stride;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int j = lane & 15, g = lane >> 4;
+    typedef double v4f64 __attribute__((ext_vector_type(4)));
+    v4f64 acc[4];
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct) acc[ct] = v4f64{0.0, 0.0, 0.0, 0.0};
+    const bool live = r0 < n && c0 < n;        // a tile outside the block: zeros
+    const int arow = tid >> 2, ak = (tid & 3) * 4;         // A tile: 64 rows x 16 k, four doubles per thread
+    const int bk = tid >> 4, bc = (tid & 15) * 4;          // B tile: 16 k x 64 columns
+    for (int k0 = 0; live && k0 < n; k0 += kSqK) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int r = r0 + arow, kk = k0 + ak + i;
+            As[arow][ak + i] = (r < n && kk < n) ? Ab[(size_t)r * ld + kk] : 0.0;
+            const int kr = k0 + bk, c = c0 + bc + i;
+            Bs[bk][bc + i] = (kr < n && c < n) ? Ab[(size_t)kr * ld + c] : 0.0;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const double a = As[16 * wave + j][4 * u + g];
+#pragma unroll
+            for (int ct = 0; ct < 4; ++ct)
+                acc[ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, Bs[4 * u + g][16 * ct + j], acc[ct], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = r0 + 16 * wave + g + 4 * r, col = c0 + 16 * ct + j;
+            if (row < n_fixed && col < n_fixed) Cb[(size_t)row * ld + col] = (row < n && col < n) ? acc[ct][r] : 0.0;
+        }
+}
 }  // namespace
 
 extern "C" {
@@ -944,7 +1025,29 @@ size_t msm_spectrum_workspace_bytes(int n_max, int p, int batch) {
     return per * (size_t)batch + 256;
 }
 
-msm_status msm_spectrum(msm_ctx* ctx, const double* d_T, int64_t t_stride, int ld, const int32_t* d_n, int n_max,
+msm_status msm_matrix_power(msm_ctx* ctx, const double* d_T, int64_t t_stride, int ld, const int32_t* d_n, int n_max,
+                            int batch, int n_squarings, double* d_scratch, double* d_out) {
+    if (!ctx) return MSM_ERR_INVALID;
+    MSM_REQUIRE(ctx, n_max >= 1 && batch >= 1 && ld >= n_max && t_stride >= (int64_t)n_max * ld - (ld - n_max),
+                "msm_matrix_power: bad shape");
+    MSM_REQUIRE(ctx, n_squarings >= 1 && n_squarings <= 6, "msm_matrix_power: need 1 <= n_squarings <= 6");
+    MSM_REQUIRE(ctx, d_T && d_out && (n_squarings == 1 || d_scratch), "msm_matrix_power: NULL pointer");
+    MSM_REQUIRE(ctx, batch <= 65535, "msm_matrix_power: batch too large for one launch");
+    const unsigned tiles = (unsigned)((n_max + kSqTile - 1) / kSqTile);
+    const double* src = d_T;
+    for (int sq = 0; sq < n_squarings; ++sq) {
+        // the last squaring lands in d_out; the ones before alternate between the two buffers
+        double* dst = ((n_squarings - 1 - sq) % 2 == 0) ? d_out : d_scratch;
+        hipLaunchKernelGGL(square_batch_kernel, dim3(tiles, tiles, (unsigned)batch), dim3(256), 0, ctx->stream, src,
+                           (size_t)t_stride, ld, d_n, n_max, dst);
+        MSM_CHECK_LAUNCH(ctx);
+        src = dst;
+    }
+    return MSM_OK;
+}
+
+static msm_status spectrum_impl(msm_ctx* ctx, const double* d_T, const double* d_iter, int64_t t_stride, int ld,
+                                const int32_t* d_n, int n_max,
                         int batch, int p, int n_iter, int init, uint64_t seed, int n_watch, void* d_workspace,
                         double* d_ritz, double* d_pi, int64_t pi_stride, double* d_change, int32_t* d_status,
                         int n_its, const double* d_lags, double* d_its_eig, double* d_its_ts, double freeze_tol,
@@ -978,12 +1081,16 @@ msm_status msm_spectrum(msm_ctx* ctx, const double* d_T, int64_t t_stride, int l
     // by lambda^q -- already q = 6 un-orthogonalised applications broke the factorisation.
     constexpr int kOrthoEvery = 1;
     ar.check_gap = n_iter;
-    auto apply = [&](const double* zin) {
+    // the ITERATIONS may run on a power of T (d_iter, msm_matrix_power: same invariant subspaces, convergence ratio to
+    // that power); the Rayleigh-Ritz step, the residuals and everything reported come from T itself
+    SpecArgs ar_it = ar;
+    if (d_iter) ar_it.T = d_iter;
+    auto apply = [&](const double* zin, const SpecArgs& aa) {
         const dim3 grid((unsigned)((n_max + 255) / 256), kSpecSplits, (unsigned)batch);
-        if (p <= 8) hipLaunchKernelGGL(spec_apply_kernel<8>, grid, dim3(kApplyThreads), 0, ctx->stream, ar, zin, partial, part_stride);
-        else if (p <= 16) hipLaunchKernelGGL(spec_apply_kernel<16>, grid, dim3(kApplyThreads), 0, ctx->stream, ar, zin, partial, part_stride);
-        else if (p <= 24) hipLaunchKernelGGL(spec_apply_kernel<24>, grid, dim3(kApplyThreads), 0, ctx->stream, ar, zin, partial, part_stride);
-        else hipLaunchKernelGGL(spec_apply_kernel<32>, grid, dim3(kApplyThreads), 0, ctx->stream, ar, zin, partial, part_stride);
+        if (p <= 8) hipLaunchKernelGGL(spec_apply_kernel<8>, grid, dim3(kApplyThreads), 0, ctx->stream, aa, zin, partial, part_stride);
+        else if (p <= 16) hipLaunchKernelGGL(spec_apply_kernel<16>, grid, dim3(kApplyThreads), 0, ctx->stream, aa, zin, partial, part_stride);
+        else if (p <= 24) hipLaunchKernelGGL(spec_apply_kernel<24>, grid, dim3(kApplyThreads), 0, ctx->stream, aa, zin, partial, part_stride);
+        else hipLaunchKernelGGL(spec_apply_kernel<32>, grid, dim3(kApplyThreads), 0, ctx->stream, aa, zin, partial, part_stride);
     };
     const size_t w_bytes = (size_t)n_max * p * sizeof(double);
     const bool lds_w = w_bytes <= 96 * 1024;
@@ -1031,6 +1138,7 @@ msm_status msm_spectrum(msm_ctx* ctx, const double* d_T, int64_t t_stride, int l
                 pa.counters = (unsigned*)((char*)ctx->aux + gram_bytes);
                 pa.error = (int*)(pa.counters + groups);
                 pa.G = G; pa.groups = groups; pa.cols = cols; pa.batch = batch; pa.n_iter = n_iter;
+                pa.twice = d_iter ? 1 : 0;
                 pa.bufA = bufA; pa.bufB = bufB;
                 MSM_HIP(ctx, hipMemsetAsync(pa.counters, 0, (size_t)groups * sizeof(unsigned) + sizeof(int), ctx->stream));
                 const size_t lds = ((size_t)n_max * (cols | 1) + (size_t)n_max * (p | 1) + (size_t)cols * p) * sizeof(double);
@@ -1049,11 +1157,11 @@ msm_status msm_spectrum(msm_ctx* ctx, const double* d_T, int64_t t_stride, int l
                 if (le == hipSuccess) {
                     const char* coop = getenv("MSM_SPEC_COOP");
                     if (coop && coop[0] == '1') {
-                        void* kargs[] = {(void*)&ar, (void*)&pa};
+                        void* kargs[] = {(void*)&ar_it, (void*)&pa};
                         le = hipLaunchCooperativeKernel((const void*)spec_persist_kernel, dim3(grid), dim3(kSolveThreads), kargs,
                                                         (unsigned)lds, ctx->stream);
                     } else {
-                        hipLaunchKernelGGL(spec_persist_kernel, dim3(grid), dim3(kSolveThreads), lds, ctx->stream, ar, pa);
+                        hipLaunchKernelGGL(spec_persist_kernel, dim3(grid), dim3(kSolveThreads), lds, ctx->stream, ar_it, pa);
                         le = hipGetLastError();
                     }
                 }
@@ -1073,9 +1181,9 @@ msm_status msm_spectrum(msm_ctx* ctx, const double* d_T, int64_t t_stride, int l
     double* cur = bufA;
     double* other = bufB;
     for (int it = 0; it < (persisted ? 0 : n_iter); ++it) {
-        apply(cur);
+        apply(cur, ar_it);
         const bool ortho = (it % kOrthoEvery) == kOrthoEvery - 1 || it == n_iter - 1;
-        const int mode = ortho ? kStepOrtho : 0;
+        const int mode = ortho ? (kStepOrtho | (d_iter && it == n_iter - 1 ? kStepTwice : 0)) : 0;
         step(mode, cur, other);   // sum -> other; ortho: orth(other) -> cur
         if (!ortho) std::swap(cur, other);
         MSM_CHECK_LAUNCH(ctx);
@@ -1084,10 +1192,32 @@ msm_status msm_spectrum(msm_ctx* ctx, const double* d_T, int64_t t_stride, int l
         MSM_HIP(ctx, hipMemcpyAsync(bufA, cur, zw * batch * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
         cur = bufA; other = bufB;
     }
-    apply(cur);
+    apply(cur, ar);
     step(kStepFinish, cur, other);
     MSM_CHECK_LAUNCH(ctx);
     return MSM_OK;
+}
+
+msm_status msm_spectrum(msm_ctx* ctx, const double* d_T, int64_t t_stride, int ld, const int32_t* d_n, int n_max,
+                        int batch, int p, int n_iter, int init, uint64_t seed, int n_watch, void* d_workspace,
+                        double* d_ritz, double* d_pi, int64_t pi_stride, double* d_change, int32_t* d_status,
+                        int n_its, const double* d_lags, double* d_its_eig, double* d_its_ts, double freeze_tol,
+                        double* d_vecs, int n_vecs) {
+    return spectrum_impl(ctx, d_T, nullptr, t_stride, ld, d_n, n_max, batch, p, n_iter, init, seed, n_watch, d_workspace,
+                         d_ritz, d_pi, pi_stride, d_change, d_status, n_its, d_lags, d_its_eig, d_its_ts, freeze_tol, d_vecs,
+                         n_vecs);
+}
+
+msm_status msm_spectrum_powered(msm_ctx* ctx, const double* d_T, const double* d_T_power, int64_t t_stride, int ld,
+                                const int32_t* d_n, int n_max, int batch, int p, int n_iter, int init, uint64_t seed,
+                                int n_watch, void* d_workspace, double* d_ritz, double* d_pi, int64_t pi_stride,
+                                double* d_change, int32_t* d_status, int n_its, const double* d_lags, double* d_its_eig,
+                                double* d_its_ts, double freeze_tol, double* d_vecs, int n_vecs) {
+    if (!ctx) return MSM_ERR_INVALID;
+    MSM_REQUIRE(ctx, d_T_power, "msm_spectrum_powered: d_T_power missing");
+    return spectrum_impl(ctx, d_T, d_T_power, t_stride, ld, d_n, n_max, batch, p, n_iter, init, seed, n_watch, d_workspace,
+                         d_ritz, d_pi, pi_stride, d_change, d_status, n_its, d_lags, d_its_eig, d_its_ts, freeze_tol, d_vecs,
+                         n_vecs);
 }
 
 }  // extern "C"

@@ -9,6 +9,7 @@ from __future__ import annotations
 
 import ctypes as C
 import os
+import sys
 from typing import Iterable, Sequence
 
 import numpy as np
@@ -965,12 +966,46 @@ class Engine:
                               noise.ptr if noise is not None else None), self.handle)
         return mse.to_host()[:F], (noise.to_host()[:F] if noise is not None else None)
 
+    def matrix_power(self, T: DeviceArray, squarings: int, *, n: DeviceArray | None = None) -> DeviceArray:
+        """T^(2^squarings) of one matrix [k,k] or a batch [B,k,k] (orders in `n`), msm_matrix_power."""
+        B = T.shape[0] if len(T.shape) == 3 else 1
+        k = T.shape[-1]
+        out = self.empty(T.shape, np.float64)
+        tmp = self.empty(T.shape, np.float64) if squarings > 1 else None
+        check(lib.msm_matrix_power(self.handle, T.ptr, k * k, k, n.ptr if n is not None else None, k, B, int(squarings),
+                                   tmp.ptr if tmp is not None else None, out.ptr), self.handle)
+        return out
+
     def spectrum(self, T: DeviceArray, *, n: DeviceArray | None = None, n_its: int = 0, lags=None,
                  p: int | None = None, want_pi: bool = True, tol: float = 1e-9, n_iter: int = 24,
                  max_launches: int = 100, seed: int = 0, allow_unconverged: bool = False, n_vecs: int = 0,
-                 n_watch: int | None = None) -> dict:
+                 n_watch: int | None = None, squarings: int | None = None) -> dict:
         """Leading Ritz values / stationary distribution / implied timescales of one matrix
-        [k,k] or a batch [B,k,k] of packed row-stochastic matrices (orders in `n`, int32 [B])."""
+        [k,k] or a batch [B,k,k] of packed row-stochastic matrices (orders in `n`, int32 [B]).
+        squarings: the subspace iterations run on T^(2^squarings) (default 2 for k >= 32: a quarter of the iterations,
+        the reported values are those of T itself); when a run on the power does not converge it is repeated on T."""
+        if squarings is None:
+            squarings = int(os.environ.get("MSM_SPEC_SQUARINGS", "2")) if T.shape[-1] >= 32 else 0
+        if squarings > 0:
+            # One matrix: a ramp of 4, 4, 8, 16, ... iterations per launch (a complex Ritz pair among the watched values is
+            # judged by its change between two launches, so there are at least two; a well-separated spectrum is done
+            # after 8 iterations on T^4); batches: two thirds of the usual number (converged matrices are frozen between
+            # launches only).  Any matrix left unconverged (or a basis T^(2^s) has made too ill-conditioned to
+            # factorise: NaN) sends the whole call to the plain iteration on T below.
+            B = T.shape[0] if len(T.shape) == 3 else 1
+            it_pow = int(os.environ.get("MSM_SPEC_NITER", -n_iter if B == 1 else max(6, (2 * n_iter) // 3)))
+            try:
+                return self._spectrum(T, self.matrix_power(T, squarings, n=n), it_pow, n=n, n_its=n_its, lags=lags, p=p,
+                                      want_pi=want_pi, tol=tol, max_launches=max(8, max_launches // 2), seed=seed,
+                                      allow_unconverged=False, n_vecs=n_vecs, n_watch=n_watch)
+            except _lib.MsmError:
+                pass
+        return self._spectrum(T, None, n_iter, n=n, n_its=n_its, lags=lags, p=p, want_pi=want_pi, tol=tol,
+                              max_launches=max_launches, seed=seed, allow_unconverged=allow_unconverged, n_vecs=n_vecs,
+                              n_watch=n_watch)
+
+    def _spectrum(self, T: DeviceArray, Tpow: DeviceArray | None, n_iter: int, *, n, n_its, lags, p, want_pi, tol,
+                  max_launches, seed, allow_unconverged, n_vecs, n_watch) -> dict:
         batched = len(T.shape) == 3
         B = T.shape[0] if batched else 1
         k = T.shape[-1]
@@ -998,18 +1033,27 @@ class Engine:
         restart = True
         since_restart = 0
         worst = prev = float("inf")
+        ramp = n_iter < 0          # negative: ramp up to |n_iter|
+        n_iter_max = abs(int(n_iter))
         for launch in range(max_launches):
-            check(lib.msm_spectrum(self.handle, T.ptr, k * k, k, n.ptr if n is not None else None, k, B, p,
-                                   int(n_iter), int(restart), int(seed), watch, ws.ptr, ritz.ptr,
-                                   pi.ptr if pi is not None else None, k, change.ptr, status.ptr, int(n_its),
-                                   lag_d.ptr, its_eig.ptr, its_ts.ptr, float(tol) if B > 1 else 0.0,
-                                   vecs.ptr if vecs is not None else None, n_vecs), self.handle)
+            n_iter = min(n_iter_max, 4 << max(0, launch - 1)) if ramp else n_iter_max
+            tail = (k * k, k, n.ptr if n is not None else None, k, B, p, int(n_iter), int(restart), int(seed), watch, ws.ptr,
+                    ritz.ptr, pi.ptr if pi is not None else None, k, change.ptr, status.ptr, int(n_its), lag_d.ptr,
+                    its_eig.ptr, its_ts.ptr, float(tol) if B > 1 else 0.0, vecs.ptr if vecs is not None else None, n_vecs)
+            if Tpow is not None:
+                check(lib.msm_spectrum_powered(self.handle, T.ptr, Tpow.ptr, *tail), self.handle)
+            else:
+                check(lib.msm_spectrum(self.handle, T.ptr, *tail), self.handle)
             launches += 1
             restart = False
             since_restart += 1
             prev, worst = worst, float(np.max(change.to_host()))
+            if os.environ.get("MSM_SPEC_TRACE") == "2":
+                print(f"  launch {launches}: worst residual {worst:.3e}", file=sys.stderr)
             if worst <= tol:
                 break
+            if Tpow is not None and not np.isfinite(worst):
+                raise _lib.MsmError("msm_spectrum: the basis broke down under the powered iteration")
             # slow convergence = the watched eigenvalues are close to lambda_{p+1}: a wider basis moves
             # that ratio down at little cost per iteration.  The decay of the worst residual between two
             # launches predicts how many more this basis needs; more than a handful -> restart with the
@@ -1025,8 +1069,12 @@ class Engine:
         else:
             if not allow_unconverged:
                 raise _lib.MsmError(
-                    f"msm_spectrum: residual {worst:.3e} > {tol:.1e} after {launches * n_iter} iterations "
+                    f"msm_spectrum: residual {worst:.3e} > {tol:.1e} after {launches} launches "
                     "(leading eigenvalues too clustered for subspace iteration)")
+        if os.environ.get("MSM_SPEC_TRACE"):
+            ch = change.to_host()
+            print(f"msm_spectrum: B={B} k={k} p={p} powered={Tpow is not None} n_iter={n_iter} launches={launches} "
+                  f"worst={worst:.2e} unconverged={int(np.sum(ch > tol))}", file=sys.stderr)
         st = status.to_host()
         if np.any(st != 0):
             raise _lib.MsmError(f"msm_spectrum: hqr did not converge (status {st.tolist()})")

@@ -287,8 +287,10 @@ def compute_implied_timescales(dtrajs: Sequence[np.ndarray], n_states: int, lag_
                     nb.view((1,), offset_elems=i), alpha=float(dirichlet_alpha), seed=seed, n_samples=S,
                     first_sample=i * S, out=batch.view((S, k, k), offset_elems=(i - a) * S * k * k))
             nrep = eng.to_device(np.repeat(nb_h[a:b], S).astype(np.int32))
+            # posterior samples have a noisy bulk right under the watched eigenvalues: the widest subspace from the start
+            # (the solver would get there after two launches and a restart)
             spec = eng.spectrum(batch, n=nrep, n_its=n, lags=np.repeat(np.asarray(lags[a:b], np.float64), S),
-                                want_pi=False, allow_unconverged=True)
+                                want_pi=False, allow_unconverged=True, p=32)
             ev_s[a:b] = spec["its_eig"].reshape(b - a, S, n)
             ts_s[a:b] = spec["its_ts"].reshape(b - a, S, n)
         tail = 50.0 * (1.0 - float(ci))                 # _its_alpha_tail_bounds :232-234

@@ -146,3 +146,60 @@ def test_clustered_spectrum_is_reported_not_guessed(engine):
         engine.spectrum(out["T"], n=out["n_active"], n_its=4, lags=[1.0], max_launches=3)
     loose = engine.spectrum(out["T"], n=out["n_active"], n_its=4, lags=[1.0], max_launches=3, allow_unconverged=True)
     assert loose["residual"][0] > 1e-9
+
+
+@pytest.mark.parametrize("k,orders,squarings", [(70, [70, 33, 1, 64], 1), (200, [200, 150, 199], 2), (500, [500], 2),
+                                                (129, [128, 129], 3)])
+def test_matrix_power_matches_numpy(engine, k, orders, squarings):
+    """msm_matrix_power: T^(2^s) of a ragged batch on the fp64 matrix cores; zeros outside each matrix's block."""
+    rng = np.random.default_rng(k)
+    B = len(orders)
+    T = np.zeros((B, k, k))
+    for b, n in enumerate(orders):
+        A = rng.random((n, n)) ** 3
+        T[b, :n, :n] = A / A.sum(1, keepdims=True)
+    nd = engine.to_device(np.asarray(orders, np.int32))
+    got = engine.matrix_power(engine.to_device(T), squarings, n=nd).to_host()
+    want = np.stack([np.linalg.matrix_power(T[b], 2 ** squarings) for b in range(B)])
+    np.testing.assert_allclose(got, want, rtol=0, atol=1e-14)
+    for b, n in enumerate(orders):
+        assert not got[b, n:, :].any() and not got[b, :, n:].any()
+    single = engine.matrix_power(engine.to_device(T[0]), squarings).to_host()
+    np.testing.assert_allclose(single, want[0], rtol=0, atol=1e-14)
+
+
+def test_spectrum_on_a_power_reports_the_values_of_T(engine):
+    """The iterations may run on T^4; Ritz values, timescales and pi are those of T (against numpy, and against the run on T)."""
+    rng = np.random.default_rng(3)
+    k = 160
+    P = np.full((k, k), 1e-3)
+    w = k // 4
+    for b in range(4):
+        P[w * b:w * b + w, w * b:w * b + w] += rng.random((w, w)) ** 2
+    P /= P.sum(1, keepdims=True)
+    Td = engine.to_device(P)
+    a = engine.spectrum(Td, n_its=4, lags=[5.0], squarings=2)
+    b_ = engine.spectrum(Td, n_its=4, lags=[5.0], squarings=0)
+    ev = np.linalg.eigvals(P)
+    ev = ev[np.argsort(-np.abs(ev))][:5].real
+    np.testing.assert_allclose(np.sort(a["its_eig"][0])[::-1], np.sort(np.abs(ev[1:5]))[::-1], rtol=1e-9)   # |real part|, as msm_spectrum reports it
+    np.testing.assert_allclose(a["its_eig"], b_["its_eig"], rtol=1e-9)
+    np.testing.assert_allclose(a["its_ts"], b_["its_ts"], rtol=1e-9)
+    np.testing.assert_allclose(a["pi"].to_host(), b_["pi"].to_host(), rtol=1e-9, atol=1e-14)
+    assert a["launches"] <= b_["launches"]
+
+
+@pytest.mark.parametrize("k,rank", [(40, 3), (64, 6), (120, 2)])
+def test_spectrum_of_low_rank_chains_with_and_without_powering(engine, k, rank):
+    """Matrices whose spectrum below the watched values is (numerically) zero: T^4 squashes those directions to the
+    rounding level, the Cholesky-QR of such a basis is the delicate case of the powered iteration.  The reported values
+    must equal numpy's either way (the powered attempt hands over to the plain iteration when it cannot converge)."""
+    rng = np.random.default_rng(k + rank)
+    memb = rng.random((k, rank)) ** 2
+    A = memb @ memb.T + 1e-3 * np.eye(k)                     # symmetric: a reversible chain, real spectrum
+    P = A / A.sum(1, keepdims=True)                          # `rank` eigenvalues of order 1, the rest ~1e-3 / row sum
+    n_its = min(4, rank - 1)
+    ev = np.sort(np.abs(np.linalg.eigvals(P).real))[::-1][1:1 + n_its]
+    for sq in (0, 2):
+        out = engine.spectrum(engine.to_device(P), n_its=n_its, lags=[1.0], squarings=sq)
+        np.testing.assert_allclose(np.sort(out["its_eig"][0])[::-1], ev, rtol=1e-7)
