@@ -147,6 +147,14 @@ msm_status msm_ctx_create(int device, void* hip_stream, msm_ctx** out) {
     }
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess) ctx->n_cu = prop.multiProcessorCount;
+    // four zeroed device words every launch may rely on: [frames scanned by the k-means filter u64 | arrival ticket of
+    // the fused centre update u32 | arrival ticket of the fused row normalisation u32] (tickets return to zero)
+    if (hipMalloc(&ctx->km_stats, 16) != hipSuccess || hipMemset(ctx->km_stats, 0, 16) != hipSuccess) {
+        if (ctx->km_stats) (void)hipFree(ctx->km_stats);
+        if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
+        delete ctx;
+        return MSM_ERR_HIP;
+    }
     *out = ctx;
     return MSM_OK;
 }

@@ -103,9 +103,8 @@ __global__ __launch_bounds__(kThreads) void absmax_kernel(const T* __restrict__ 
     }
 }
 
-__global__ void fit_scale_kernel(const unsigned long long* __restrict__ absmax_bits, double n_total, double tol2,
-                                 FitState* __restrict__ st) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+__device__ __forceinline__ void fit_scale_body(const unsigned long long* __restrict__ absmax_bits, double n_total,
+                                               double tol2, FitState* __restrict__ st) {
     double amax = __longlong_as_double((long long)*absmax_bits);
     if (!(amax > 0.0)) amax = 1.0;
     // 2^e * n_total * amax < 2^62
@@ -122,12 +121,21 @@ __global__ void fit_scale_kernel(const unsigned long long* __restrict__ absmax_b
     st->inertia = 0.0;
 }
 
+__global__ void fit_scale_kernel(const unsigned long long* __restrict__ absmax_bits, double n_total, double tol2,
+                                 FitState* __restrict__ st) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    fit_scale_body(absmax_bits, n_total, tol2, st);
+}
+
 // centres[j] = whitened frame floor((j + u_j) * n / k), u_j = hash(seed, j) in [0, 1)
 template <typename T>
 __global__ void init_centers_kernel(const T* __restrict__ x, int64_t n, int d, int64_t ld,
                                     const double* __restrict__ mean, const double* __restrict__ stdv, int k,
-                                    unsigned long long seed, double* __restrict__ centers) {
+                                    unsigned long long seed, double* __restrict__ centers,
+                                    const unsigned long long* __restrict__ absmax_bits, double n_total, double tol2,
+                                    FitState* __restrict__ st) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i == 0 && st) fit_scale_body(absmax_bits, n_total, tol2, st);     // (fit_scale_kernel's job, one launch less)
     if (i >= k * d) return;
     const int j = i / d, f = i - j * d;
     unsigned long long h = seed + 0x9E3779B97F4A7C15ull * (unsigned long long)(j + 1);  // splitmix64
@@ -1128,16 +1136,20 @@ msm_status msm_kmeans_fit_begin(msm_ctx* ctx, const void* d_x, msm_dtype dtype, 
                                d, ld, d_mean, d_std, bits);
         MSM_CHECK_LAUNCH(ctx);
     }
-    hipLaunchKernelGGL(fit_scale_kernel, dim3(1), dim3(64), 0, ctx->stream, bits, n_total, tol2, (FitState*)d_state);
-    MSM_CHECK_LAUNCH(ctx);
+    if (!init_centers) {
+        hipLaunchKernelGGL(fit_scale_kernel, dim3(1), dim3(64), 0, ctx->stream, bits, n_total, tol2, (FitState*)d_state);
+        MSM_CHECK_LAUNCH(ctx);
+    }
     if (init_centers) {
         const int g2 = msm_ceil_div((int64_t)k * d, 256);
         if (dtype == MSM_F32)
             hipLaunchKernelGGL(init_centers_kernel<float>, dim3(g2), dim3(256), 0, ctx->stream, (const float*)d_x, n, d,
-                               ld, d_mean, d_std, k, (unsigned long long)seed, d_centers);
+                               ld, d_mean, d_std, k, (unsigned long long)seed, d_centers, bits, n_total, tol2,
+                               (FitState*)d_state);
         else
             hipLaunchKernelGGL(init_centers_kernel<double>, dim3(g2), dim3(256), 0, ctx->stream, (const double*)d_x, n,
-                               d, ld, d_mean, d_std, k, (unsigned long long)seed, d_centers);
+                               d, ld, d_mean, d_std, k, (unsigned long long)seed, d_centers, bits, n_total, tol2,
+                               (FitState*)d_state);
         MSM_CHECK_LAUNCH(ctx);
     }
     return MSM_OK;

@@ -119,6 +119,60 @@ __global__ __launch_bounds__(1024) void diag_mass_kernel(const double* __restric
     }
 }
 
+// mode 0 in ONE launch: row sums (the additions of rowcol_sums_kernel, in its order), T = C / row sum (build_T_kernel's
+// expression) and trace(T) / k (diag_mass_kernel's additions over its 1024 threads, by the workgroup that finishes last:
+// the diagonal entries travel as device-scope stores, every workgroup waits for the acknowledgement of its own before it
+// takes a ticket).  Same bits as the three launches it replaces.
+template <typename CT>
+__global__ __launch_bounds__(kThreads) void row_normalise_kernel(const CT* __restrict__ C, int k, double* __restrict__ rowsum,
+                                                                double* __restrict__ T, double* tdiag,
+                                                                unsigned int* __restrict__ ticket,
+                                                                double* __restrict__ diag_out) {
+    __shared__ double red[16];
+    __shared__ double rs_sh;
+    __shared__ int is_last;
+    const int i = blockIdx.x;
+    double r = 0.0;
+    for (int j = threadIdx.x; j < k; j += kThreads) r += cnt_as_f64(C[(size_t)i * k + j]);
+    for (int off = 32; off > 0; off >>= 1) r += __shfl_down(r, off, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = r;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double tr = 0.0;
+        for (int w = 0; w < kThreads / 64; ++w) tr += red[w];
+        rowsum[i] = tr;
+        rs_sh = tr;
+    }
+    __syncthreads();
+    const double rs = rs_sh;
+    for (int j = threadIdx.x; j < k; j += kThreads)
+        T[(size_t)i * k + j] = rs > 0.0 ? cnt_as_f64(C[(size_t)i * k + j]) / rs : 0.0;
+    if (!diag_out) return;
+    if (threadIdx.x == 0) {
+        const double tii = rs > 0.0 ? cnt_as_f64(C[(size_t)i * k + i]) / rs : 0.0;
+        __hip_atomic_store(&tdiag[i], tii, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const unsigned t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        is_last = t == gridDim.x - 1;
+        if (is_last) __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+    if (!is_last) return;
+    for (int v0 = 0; v0 < 1024; v0 += kThreads) {          // diag_mass_kernel's 1024 threads, kThreads at a time
+        const int v = v0 + threadIdx.x;
+        double t = 0.0;
+        for (int q = v; q < k; q += 1024) t += __hip_atomic_load(&tdiag[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        for (int off = 32; off > 0; off >>= 1) t += __shfl_down(t, off, 64);
+        if ((v & 63) == 0) red[v >> 6] = t;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double s = 0.0;
+        for (int w = 0; w < 16; ++w) s += red[w];
+        *diag_out = k > 0 ? s / (double)k : __builtin_nan("");
+    }
+}
+
 // T_full = I with the active block; pi_full = 0 outside the active set (_estimation.py:174-181)
 __global__ __launch_bounds__(kThreads) void embed_full_kernel(const double* __restrict__ T_act,
                                                              const double* __restrict__ pi_act,
@@ -974,6 +1028,17 @@ msm_status msm_transition_matrix(msm_ctx* ctx, const void* d_counts, int counts_
     msm_status rs = msm_reserve_scratch(ctx, (size_t)k * sizeof(double));
     if (rs != MSM_OK) return rs;
     double* colsum = (double*)ctx->scratch;
+    if (mode == 0 && ctx->km_stats) {        // one launch (the scratch holds the diagonal instead of the column sums)
+        unsigned int* ticket = (unsigned int*)ctx->km_stats + 3;
+        if (counts_are_f64)
+            hipLaunchKernelGGL(row_normalise_kernel<double>, dim3(k), dim3(kThreads), 0, ctx->stream, (const double*)d_counts, k,
+                               d_rowsum, d_T, colsum, ticket, d_diag_mass);
+        else
+            hipLaunchKernelGGL(row_normalise_kernel<long long>, dim3(k), dim3(kThreads), 0, ctx->stream,
+                               (const long long*)d_counts, k, d_rowsum, d_T, colsum, ticket, d_diag_mass);
+        MSM_CHECK_LAUNCH(ctx);
+        return MSM_OK;
+    }
     if (counts_are_f64)
         hipLaunchKernelGGL(rowcol_sums_kernel<double>, dim3(k), dim3(kThreads), 0, ctx->stream, (const double*)d_counts, k,
                            d_rowsum, colsum);
