@@ -223,6 +223,7 @@ struct SpecArgs {
     double* vecs;         // [batch][n_vecs][n_fixed]
     int n_vecs;
     const int* persist_error;   // set by spec_persist_kernel when a group barrier timed out (NULL: not used)
+    int splits;           // row splits of T per product launch, 1 .. kSpecSplits (set by the host from the batch size)
 };
 
 // Batches converge unevenly (a lag scan, posterior samples): once a matrix has met the caller's
@@ -273,41 +274,52 @@ __device__ double spec_block_max(double v, SpecShared* sh) {
     return sh->bc;
 }
 
-// Gram matrix M = A'B (p x p): thread (pair, group) partial sums over rows j = g, g + groups, ...,
-// then a fixed-order reduce through LDS scratch.  Inlined so that an LDS-resident operand keeps
-// its address space (ds_read instead of flat loads); 32-bit strength-reduced offsets -- the
-// single workgroup is bound by instruction issue, not by the 2 n p^2 flops.
+// Gram matrix M = A'B (p x p, operands n x p with row stride p) on the fp64 matrix cores.  The scalar version (a thread
+// per entry walking all rows) read every operand element p times from the LDS: 8 us at n = 200, p = 32, LDS-bandwidth
+// bound.  Here a wave takes a 16 x 16 tile of M and a share of the rows (16 rows per trip: four v_mfma_f64_16x16x4
+// whose operand reads go out together); the shares of a tile are added in share order.  scratch: LDS, >= 3 kMaxP^2 doubles.
+typedef double spec_v4f64 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ void spec_gram_fast(const double* __restrict__ A, const double* __restrict__ B, int n, int p,
-                                               double* M, double* scratch /* >= blockDim.x doubles (LDS) */) {
-    const int pairs = p * p;
-    const int groups = blockDim.x / pairs;  // >= 1 because p <= 32 and blockDim = 1024
-    const int tid = threadIdx.x;
-    const int pr = tid % pairs, g = tid / pairs;
-    if (g < groups) {
-        const int a = pr / p, b = pr - a * p;
-        // 8 independent row pairs in flight (the sum order stays fixed: 8 interleaved partial
-        // sums, then their sum)
-        double part[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
-        const int step = groups * p, end = n * p;
-        int off = g * p;
-        for (; off + 7 * step < end; off += 8 * step) {
-            double av[8], bv[8];
+                                               double* M, double* scratch) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    const int j = lane & 15, g = lane >> 4;
+    const int tp = (p + 15) >> 4, tiles = tp * tp;
+    const int shares = max(1, min(nw / tiles, (3 * kMaxP * kMaxP) / (tiles * 256)));   // row shares per tile
+    const int trips = (n + 15) >> 4;
+    const int trips_per_share = (trips + shares - 1) / shares;
+    if (wave < tiles * shares) {
+        const int t = wave % tiles, sh_id = wave / tiles;
+        const int a0 = (t / tp) * 16, b0 = (t - (t / tp) * tp) * 16;
+        const bool aok = a0 + j < p, bok = b0 + j < p;
+        const int ac = aok ? a0 + j : 0, bc = bok ? b0 + j : 0;
+        spec_v4f64 acc = {0.0, 0.0, 0.0, 0.0};
+        const int k_begin = sh_id * trips_per_share * 16, k_end = min(n, k_begin + trips_per_share * 16);
+        for (int k0 = k_begin; k0 < k_end; k0 += 16) {
+            double av[4], bv[4];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                av[u] = A[off + u * step + a];
-                bv[u] = B[off + u * step + b];
+            for (int u = 0; u < 4; ++u) {
+                const int k = k0 + 4 * u + g;
+                const bool kok = k < k_end;
+                const int kk = kok ? k : 0;
+                av[u] = A[kk * p + ac];
+                bv[u] = B[kk * p + bc];
+                if (!(aok && kok)) av[u] = 0.0;
+                if (!(bok && kok)) bv[u] = 0.0;
             }
 #pragma unroll
-            for (int u = 0; u < 8; ++u) part[u] = fma(av[u], bv[u], part[u]);
+            for (int u = 0; u < 4; ++u) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u], bv[u], acc, 0, 0, 0);
         }
-        for (; off < end; off += step) part[0] = fma(A[off + a], B[off + b], part[0]);
-        scratch[tid] = ((part[0] + part[1]) + (part[2] + part[3])) + ((part[4] + part[5]) + (part[6] + part[7]));
+        double* part = scratch + (size_t)(sh_id * tiles + t) * 256;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) part[(g + 4 * r) * 16 + j] = acc[r];
     }
     __syncthreads();
-    if (tid < pairs) {
-        double t = 0.0;
-        for (int gg = 0; gg < groups; ++gg) t += scratch[gg * pairs + tid];
-        M[tid] = t;
+    for (int e = threadIdx.x; e < p * p; e += blockDim.x) {
+        const int a = e / p, b = e - a * p;
+        const int t = (a >> 4) * tp + (b >> 4), off = (a & 15) * 16 + (b & 15);
+        double v = 0.0;
+        for (int s2 = 0; s2 < shares; ++s2) v += scratch[(size_t)(s2 * tiles + t) * 256 + off];
+        M[e] = v;
     }
     __syncthreads();
 }
@@ -344,7 +356,9 @@ __device__ void spec_ritz(SpecShared* sh, int p, double* out_re, double* out_im)
 // by a light single-workgroup step per matrix (sum of the row-split partials, and every few
 // steps Gram + Cholesky-QR; Rayleigh-Ritz / residuals / pi / implied timescales at the end).
 // T is stochastic (|lambda| <= 1) so the basis needs no rescaling between orthogonalisations.
-constexpr int kSpecSplits = 16;       // row splits of T per apply launch (fixed-order partial sums)
+constexpr int kSpecSplits = 16;       // most row splits of T per apply launch (fixed-order partial sums); a large batch
+                                      // fills the chip without splitting and takes 1: a sixteenth of the partial-product
+                                      // traffic (C4: 4 GB written and read back per iteration with 16)
 constexpr int kApplyThreads = 256;    // 4 waves = 4 tiles of 64 columns
 
 // partial[s][j][c] = sum_{i in split s} T[i][j] Z[i][c]
@@ -361,7 +375,7 @@ __global__ __launch_bounds__(kApplyThreads) void spec_apply_kernel(SpecArgs ar, 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int j = (blockIdx.x * 4 + wave) * 64 + lane;
-    const int rows = (n + kSpecSplits - 1) / kSpecSplits;
+    const int rows = (n + ar.splits - 1) / ar.splits;
     const int i0 = blockIdx.y * rows, i1 = min(n, i0 + rows);
     double acc[PC];
 #pragma unroll
@@ -413,67 +427,124 @@ constexpr int kStepFinish = 8;   // Rayleigh-Ritz, residuals, pi, implied timesc
 
 // Z = W R^-1 for upper-triangular R (p x p in LDS): R^-1 by one wave (lane = column), then a
 // p-term dot product per element.
-// R^-1 (upper) of the Cholesky factor in LDS by one wave, lane = column (back substitution)
-__device__ __forceinline__ void rinv_wave(const double* R, double* Rinv, int p) {
-    const int c = threadIdx.x & 63;
-    if (c < p) {
-        for (int m = 0; m < p; ++m) Rinv[m * p + c] = 0.0;
-        Rinv[c * p + c] = 1.0 / R[c * p + c];
-        for (int m = c - 1; m >= 0; --m) {
-            double a = 0.0;
-            for (int l = m + 1; l <= c; ++l) a = fma(R[m * p + l], Rinv[l * p + c], a);
-            Rinv[m * p + c] = -a / R[m * p + m];
+// Cholesky factor R (upper, G = R'R) of the p x p Gram matrix (both in LDS, row stride p) by ONE wave: lane j keeps
+// column j of R in registers (compile-time indices through template recursion -- `#pragma unroll` with a break left the
+// arrays in scratch memory), the pivot-row elements come by v_readlane, and the dependent chain holds only the
+// multiply-adds, the square root and the division: 13 instead of 21 us at p = 32, 3.7 instead of 5.5 us at p = 12
+// (tools/run/spec_stamps.sh).  Same operations in the same order as the LDS walk it replaces: the same bits.
+__device__ __forceinline__ double readlane_f64(double v, int lane) {
+    const long long b = __double_as_longlong(v);
+    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)b, lane);
+    const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(b >> 32), lane);
+    return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+template <int C>
+__device__ __forceinline__ void chol_step(double (&r)[kMaxP], const double* G, double* R, int p, int j) {
+    if constexpr (C < kMaxP) {
+        if (C < p) {
+            double v = (j < p && j >= C) ? G[C * p + j] : 0.0;
+#pragma unroll
+            for (int m = 0; m < C; ++m) v = fma(-readlane_f64(r[m], C), r[m], v);
+            double diag = readlane_f64(v, C);
+            if (!(diag > 1e-300)) diag = 1e-300;
+            const double rcc = sqrt(diag);
+            r[C] = j > C ? v / rcc : (j == C ? rcc : 0.0);
+            if (j < p) R[C * p + j] = r[C];
+            chol_step<C + 1>(r, G, R, p, j);
         }
     }
 }
-
-// Cholesky factor R (upper, G = R'R) of the p x p Gram matrix in LDS by one wave, lane = column.  (A version with the
-// columns in registers and readlane broadcasts -- no LDS round trip in the dependent chain, same bits -- measured no
-// faster at p = 12 or 32: the factorisations are not what bounds an orthogonalisation step.)
 __device__ __forceinline__ void chol_wave(const double* G, double* R, int p) {
-    const int j = threadIdx.x & 63;
-    for (int c = 0; c < p; ++c) {
-        double v = 0.0;
-        if (j < p && j >= c) {
-            v = G[c * p + j];
-            for (int m = 0; m < c; ++m) v = fma(-R[m * p + c], R[m * p + j], v);
-        }
-        double diag = __shfl(v, c, 64);
-        if (!(diag > 1e-300)) diag = 1e-300;  // rank-deficient basis: keep going, column dies out
-        const double rcc = sqrt(diag);
-        if (j < p) R[c * p + j] = j > c ? v / rcc : (j == c ? rcc : 0.0);
-        __builtin_amdgcn_wave_barrier();
-    }
+    double r[kMaxP];
+    chol_step<0>(r, G, R, p, threadIdx.x & 63);
 }
 
-__device__ __forceinline__ void spec_apply_rinv(SpecShared* sh, int p, const double* __restrict__ W,
-                                                double* __restrict__ Z, int n) {
-    const int tid = threadIdx.x;
-    double* Rinv = sh->Hw;  // p x p
-    if (tid < 64) rinv_wave(sh->R, Rinv, p);
-    __syncthreads();
-    // one row per thread: the whole row of W is requested at once (independent loads), every
-    // output is a short FMA chain over registers and the LDS copy of R^-1
-    for (int i = tid; i < n; i += blockDim.x) {
-        double w[kMaxP];
-        const int row = i * p;
+// R^-1 (upper) by one wave, lane c = column c by back substitution, from a copy of R padded with zeros (ones on the
+// diagonal) to PM x PM: no guards inside the sums, so every LDS read has a compile-time address and leaves the dependent
+// chain (the walk over the compact copy paid an LDS round trip per term: 19 us at p = 32).  The padded terms add
+// fma(0, x, a) = a: the bits of the compact walk.
+template <int PM, int M>
+__device__ __forceinline__ void rinv_pad_step(double (&x)[PM], const double* Rp, int c) {
+    if constexpr (M >= 0) {
+        double a = 0.0;
 #pragma unroll
-        for (int m = 0; m < kMaxP; ++m) w[m] = m < p ? W[row + m] : 0.0;
+        for (int l = M + 1; l < PM; ++l) a = fma(Rp[M * PM + l], x[l], a);      // x[l] = 0 for l > c
+        const double num = c == M ? 1.0 : -a;
+        x[M] = M <= c ? num / Rp[M * PM + M] : 0.0;
+        rinv_pad_step<PM, M - 1>(x, Rp, c);
+    }
+}
+template <int PM>
+__device__ __forceinline__ void rinv_wave_pad(const double* R, double* Rpad, double* Rinv, int p) {
+    const int c = threadIdx.x & 63;
+    for (int e = c; e < PM * PM; e += 64) {
+        const int m = e / PM, l = e - m * PM;
+        Rpad[e] = (m < p && l < p) ? R[m * p + l] : (m == l ? 1.0 : 0.0);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    double x[PM];
+    rinv_pad_step<PM, PM - 1>(x, Rpad, c);
+    if (c < p) {
 #pragma unroll
-        for (int c8 = 0; c8 < kMaxP; c8 += 8) {
-            if (c8 >= p) break;
+        for (int m = 0; m < PM; ++m)
+            if (m < p) Rinv[m * p + c] = x[m];
+    }
+}
+// Rpad: LDS work space of kMaxP^2 doubles (the Gram matrix is no longer needed when this runs)
+__device__ __forceinline__ void rinv_wave(const double* R, double* Rpad, double* Rinv, int p) {
+    if (p <= 16) rinv_wave_pad<16>(R, Rpad, Rinv, p);
+    else rinv_wave_pad<kMaxP>(R, Rpad, Rinv, p);
+}
+
+// Z = W Rinv (n x p times the upper-triangular p x p in LDS) on the matrix cores: a wave takes 16 rows and all their
+// columns (two accumulator tiles at most), so W and Z may be the same array.  The scalar version kept one row per
+// thread and walked R^-1 element by element behind LDS latency: 35 us at n = 200, p = 32 with a fifth of the threads busy.
+__device__ __forceinline__ void spec_times_rinv(const double* Rinv, int p, const double* W, double* Z, int n) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    const int j = lane & 15, g = lane >> 4;
+    const int tp = (p + 15) >> 4;     // 1 or 2
+    for (int rb = wave; rb * 16 < n; rb += nw) {
+        const int i0 = rb * 16;
+        const bool rok = i0 + j < n;
+        const int ri = rok ? i0 + j : 0;
+        spec_v4f64 acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
+        for (int k0 = 0; k0 < p; k0 += 16) {
+            double av[4], b0[4], b1[4];
 #pragma unroll
-            for (int c = c8; c < c8 + 8; ++c) {
-                if (c < p) {
-                    double v = 0.0;
+            for (int u = 0; u < 4; ++u) {
+                const int k = k0 + 4 * u + g;
+                const bool kok = k < p;
+                const int kk = kok ? k : 0;
+                av[u] = W[ri * p + kk];
+                if (!(rok && kok)) av[u] = 0.0;
+                b0[u] = (kok && j < p) ? Rinv[kk * p + (j < p ? j : 0)] : 0.0;
+                b1[u] = (kok && 16 + j < p) ? Rinv[kk * p + (16 + j < p ? 16 + j : 0)] : 0.0;
+            }
 #pragma unroll
-                    for (int m = 0; m <= c; ++m) v = fma(w[m], Rinv[m * p + c], v);
-                    Z[row + c] = v;
-                }
+            for (int u = 0; u < 4; ++u) {
+                acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u], b0[u], acc0, 0, 0, 0);
+                if (tp > 1) acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u], b1[u], acc1, 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = i0 + g + 4 * r;
+            if (row < n) {
+                if (j < p) Z[row * p + j] = acc0[r];
+                if (16 + j < p) Z[row * p + 16 + j] = acc1[r];
             }
         }
     }
     __syncthreads();
+}
+
+__device__ __forceinline__ void spec_apply_rinv(SpecShared* sh, int p, const double* W, double* Z, int n) {
+    double* Rinv = sh->Hw;  // p x p
+    if (threadIdx.x < 64) rinv_wave(sh->R, sh->G, Rinv, p);
+    __syncthreads();
+    spec_times_rinv(Rinv, p, W, Z, n);
 }
 
 __device__ void spec_cholesky(SpecShared* sh, int p) {
@@ -639,7 +710,7 @@ __global__ __launch_bounds__(kSolveThreads) void spec_persist_kernel(SpecArgs ar
             }
             persist_cholesky(&sh, p);
             double* Rinv = sh.Rinv;     // R^-1 by one wave (lane = column)
-            if (tid < 64) rinv_wave(sh.R, Rinv, p);
+            if (tid < 64) rinv_wave(sh.R, sh.G, Rinv, p);
             __syncthreads();
             // Z = W R^-1, row by row in place (a thread owns a row: no hazard)
             for (int i = tid; i < n; i += kSolveThreads) {
@@ -665,33 +736,8 @@ __global__ __launch_bounds__(kSolveThreads) void spec_persist_kernel(SpecArgs ar
     }
 }
 
-// Z <- Z R^-1 in place (a thread owns a row and has read all of it before it writes)
-__device__ __forceinline__ void spec_apply_rinv_inplace(SpecShared* sh, int p, double* Z, int n) {
-    const int tid = threadIdx.x;
-    double* Rinv = sh->Hw;  // p x p
-    if (tid < 64) rinv_wave(sh->R, Rinv, p);
-    __syncthreads();
-    for (int i = tid; i < n; i += blockDim.x) {
-        double w[kMaxP];
-        const int row = i * p;
-#pragma unroll
-        for (int m = 0; m < kMaxP; ++m) w[m] = m < p ? Z[row + m] : 0.0;
-        double out[kMaxP];
-#pragma unroll
-        for (int c = 0; c < kMaxP; ++c) {
-            double v = 0.0;
-            if (c < p) {
-#pragma unroll
-                for (int m = 0; m <= c; ++m) v = fma(w[m], Rinv[m * p + c], v);
-            }
-            out[c] = v;
-        }
-#pragma unroll
-        for (int c = 0; c < kMaxP; ++c)
-            if (c < p) Z[row + c] = out[c];
-    }
-    __syncthreads();
-}
+// Z <- Z R^-1 in place (a wave reads all of its 16 rows before it writes them)
+__device__ __forceinline__ void spec_apply_rinv_inplace(SpecShared* sh, int p, double* Z, int n) { spec_apply_rinv(sh, p, Z, Z, n); }
 
 // Z: current (orthonormal unless between orthogonalisations) basis; Wb: the other buffer.
 template <bool lds_w>
@@ -752,24 +798,43 @@ __global__ __launch_bounds__(kSolveThreads) void spec_step_kernel(SpecArgs ar, i
         const double* part = partial_all + (size_t)b * part_stride;
         const size_t split_stride = (size_t)ar.n_fixed * ar.p;
         int e = tid;
-        for (; e + (int)blockDim.x < n * p; e += 2 * blockDim.x) {  // 2 x kSpecSplits loads in flight
-            double v0[kSpecSplits], v1[kSpecSplits];
+        if (ar.splits == kSpecSplits) {
+            for (; e + (int)blockDim.x < n * p; e += 2 * blockDim.x) {  // 2 x kSpecSplits loads in flight
+                double v0[kSpecSplits], v1[kSpecSplits];
 #pragma unroll
-            for (int sp = 0; sp < kSpecSplits; ++sp) {
-                v0[sp] = part[sp * split_stride + e];
-                v1[sp] = part[sp * split_stride + e + blockDim.x];
+                for (int sp = 0; sp < kSpecSplits; ++sp) {
+                    v0[sp] = part[sp * split_stride + e];
+                    v1[sp] = part[sp * split_stride + e + blockDim.x];
+                }
+                double a0 = 0.0, a1 = 0.0;
+#pragma unroll
+                for (int sp = 0; sp < kSpecSplits; ++sp) { a0 += v0[sp]; a1 += v1[sp]; }
+                W[e] = a0;
+                W[e + blockDim.x] = a1;
             }
-            double a0 = 0.0, a1 = 0.0;
+            for (; e < n * p; e += blockDim.x) {
+                double v = 0.0;
 #pragma unroll
-            for (int sp = 0; sp < kSpecSplits; ++sp) { a0 += v0[sp]; a1 += v1[sp]; }
-            W[e] = a0;
-            W[e + blockDim.x] = a1;
-        }
-        for (; e < n * p; e += blockDim.x) {
-            double v = 0.0;
+                for (int sp = 0; sp < kSpecSplits; ++sp) v += part[sp * split_stride + e];
+                W[e] = v;
+            }
+        } else {
+            // few splits (large batches: one): eight elements in flight per thread
+            for (; e + 7 * (int)blockDim.x < n * p; e += 8 * blockDim.x) {
+                double a[8];
 #pragma unroll
-            for (int sp = 0; sp < kSpecSplits; ++sp) v += part[sp * split_stride + e];
-            W[e] = v;
+                for (int q = 0; q < 8; ++q) a[q] = part[e + q * blockDim.x];
+                for (int sp = 1; sp < ar.splits; ++sp)
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) a[q] += part[sp * split_stride + e + q * blockDim.x];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) W[e + q * blockDim.x] = a[q];
+            }
+            for (; e < n * p; e += blockDim.x) {
+                double v = part[e];
+                for (int sp = 1; sp < ar.splits; ++sp) v += part[sp * split_stride + e];
+                W[e] = v;
+            }
         }
         __syncthreads();
         if (lds_w && !(mode & (kStepOrtho | kStepFinish))) {  // plain power step: the next apply reads global
@@ -1140,6 +1205,10 @@ static msm_status spectrum_impl(msm_ctx* ctx, const double* d_T, const double* d
     ar.vecs = d_vecs; ar.n_vecs = n_vecs;
     ar.status = d_status; ar.n_its = n_its; ar.lags = d_lags; ar.its_eig = d_its_eig; ar.its_ts = d_its_ts;
     ar.persist_error = nullptr;
+    {   // enough workgroups for the product to fill the chip four times over, no more splits than that needs
+        const int64_t per_split = (int64_t)((n_max + 255) / 256) * batch;
+        ar.splits = (int)std::max<int64_t>(1, std::min<int64_t>(kSpecSplits, (4 * (int64_t)ctx->n_cu + per_split - 1) / per_split));
+    }
     // orthogonalise every kOrthoEvery applications and always after the last one; compare the
     // complex Ritz values against those right after an earlier orthogonalisation.  Every step:
     // Cholesky-QR squares the condition number of W, and a metastable T damps the fast directions
@@ -1151,7 +1220,7 @@ static msm_status spectrum_impl(msm_ctx* ctx, const double* d_T, const double* d
     SpecArgs ar_it = ar;
     if (d_iter) ar_it.T = d_iter;
     auto apply = [&](const double* zin, const SpecArgs& aa) {
-        const dim3 grid((unsigned)((n_max + 255) / 256), kSpecSplits, (unsigned)batch);
+        const dim3 grid((unsigned)((n_max + 255) / 256), (unsigned)aa.splits, (unsigned)batch);
         if (p <= 8) hipLaunchKernelGGL(spec_apply_kernel<8>, grid, dim3(kApplyThreads), 0, ctx->stream, aa, zin, partial, part_stride);
         else if (p <= 16) hipLaunchKernelGGL(spec_apply_kernel<16>, grid, dim3(kApplyThreads), 0, ctx->stream, aa, zin, partial, part_stride);
         else if (p <= 24) hipLaunchKernelGGL(spec_apply_kernel<24>, grid, dim3(kApplyThreads), 0, ctx->stream, aa, zin, partial, part_stride);
