@@ -499,9 +499,10 @@ msm_status msm_embed_full(msm_ctx* ctx, const double* d_T_active, const double* 
  *   d_ritz   f64 [batch][128] = {re[32] | im[32] | previous call's re[32] | im[32]},
  *            Ritz values sorted by descending magnitude (the caller keeps the buffer between calls)
  *   d_change f64 [batch]: convergence measure of the top n_watch Ritz values -- the residual
- *            ||T'x - theta x|| / ||x|| of every real Ritz pair, for a complex value its relative
- *            change since the previous call (1 right after init) -- the caller relaunches with
- *            init = 0 until it is small
+ *            ||T'x - theta x|| / ||x|| of every Ritz pair (complex pairs in real arithmetic through the
+ *            real invariant plane; for them the smaller of the residual and the relative change of
+ *            the value since the previous call counts) -- the caller relaunches with init = 0 until
+ *            it is small
  *   d_pi     f64 [batch][pi_stride] stationary distribution (sum 1), or NULL
  *   n_its>0: d_its_eig / d_its_ts f64 [batch][n_its]: the top (n_its+1) values re-sorted by
  *            descending real part, first dropped, |real part| clipped to [1e-12, 1-1e-12],

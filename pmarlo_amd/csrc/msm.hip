@@ -739,6 +739,26 @@ __global__ __launch_bounds__(kSolveThreads) void spec_persist_kernel(SpecArgs ar
 // Z <- Z R^-1 in place (a wave reads all of its 16 rows before it writes them)
 __device__ __forceinline__ void spec_apply_rinv_inplace(SpecShared* sh, int p, double* Z, int n) { spec_apply_rinv(sh, p, Z, Z, n); }
 
+// Complex Ritz pairs theta = a +- i b get a true residual like the real ones (their change between two launches was
+// the measure before: a solve with a complex pair among the watched values could not finish in one launch).  A pair whose
+// imaginary part is at rounding level relative to its size keeps the change measure (the partner vector divides by b).
+__device__ __forceinline__ bool spec_complex_ok(double a, double b) { return fabs(b) > 1e-7 * fmax(1.0, fabs(a)); }
+// v = (a u - H u) / b by one wave (all lanes call it; u, v: p doubles in LDS, v must not alias u)
+__device__ __forceinline__ void spec_complex_partner(const double* H, int p, double a, double b, const double* u, double* v) {
+    const int lane = threadIdx.x & 63;
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    double hv = 0.0;
+    if (lane < p)
+        for (int c = 0; c < p; ++c) hv = fma(H[lane * p + c], u[c], hv);
+    const double out = lane < p ? (a * u[lane] - hv) / b : 0.0;
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    if (lane < p) v[lane] = out;
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
 // Z: current (orthonormal unless between orthogonalisations) basis; Wb: the other buffer.
 template <bool lds_w>
 __global__ __launch_bounds__(kSolveThreads) void spec_step_kernel(SpecArgs ar, int mode, double* __restrict__ Zall,
@@ -890,6 +910,11 @@ __global__ __launch_bounds__(kSolveThreads) void spec_step_kernel(SpecArgs ar, i
         const int w = tid >> 6;
         if (w < nw && ritz[kMaxP + w] == 0.0)
             small_eig::eigenvector_wave(sh.H, p, p, ritz[w], sh.Hw + w * per, sh.Hw + w * per + p);
+        else if (w < nw && spec_complex_ok(ritz[w], ritz[kMaxP + w])) {
+            double* u = sh.Hw + w * per;
+            small_eig::eigenvector_wave(sh.H, p, p, ritz[w], u, u + p, ritz[kMaxP + w]);
+            spec_complex_partner(sh.H, p, ritz[w], ritz[kMaxP + w], u, u + p);      // v into the (now free) work space
+        }
         else if (w == nw && ar.pi)
             small_eig::eigenvector_wave(sh.H, p, p, sh.wr[pi_id], sh.Hw + w * per, sh.Hw + w * per + p);
         __syncthreads();
@@ -899,6 +924,48 @@ __global__ __launch_bounds__(kSolveThreads) void spec_step_kernel(SpecArgs ar, i
         for (int wv = 0; wv < nw; ++wv) {
             const double th_re = ritz[wv], th_im = ritz[kMaxP + wv];
             if (th_im != 0.0) {
+                if (spec_complex_ok(th_re, th_im)) {
+                    // true residual of the complex pair x = Z (u + i v):  T'x - theta x  in real arithmetic
+                    const double* uv = sh.Hw + wv * per;       // [u p | v p]
+                    if (!side_by_side) {
+                        if (tid < 64) {
+                            small_eig::eigenvector_wave(sh.H, p, p, th_re, sh.y, sh.Hw + p, th_im);
+                            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+                            __builtin_amdgcn_wave_barrier();
+                            for (int c = tid; c < p; c += 64) sh.Hw[c] = sh.y[c];
+                            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+                            __builtin_amdgcn_wave_barrier();
+                            spec_complex_partner(sh.H, p, th_re, th_im, sh.Hw, sh.Hw + p);
+                        }
+                        __syncthreads();
+                        uv = sh.Hw;
+                    }
+                    double rn = 0.0, xn = 0.0;
+                    for (int i = tid; i < n; i += blockDim.x) {
+                        double xr = 0.0, xi = 0.0, tr = 0.0, ti = 0.0;
+                        for (int c = 0; c < p; ++c) {
+                            const double z = Z[(size_t)i * p + c], w_ = W[(size_t)i * p + c];
+                            xr = fma(z, uv[c], xr);
+                            xi = fma(z, uv[p + c], xi);
+                            tr = fma(w_, uv[c], tr);
+                            ti = fma(w_, uv[p + c], ti);
+                        }
+                        const double rr = tr - (th_re * xr - th_im * xi), ri = ti - (th_im * xr + th_re * xi);
+                        rn = fma(rr, rr, fma(ri, ri, rn));
+                        xn = fma(xr, xr, fma(xi, xi, xn));
+                    }
+                    rn = spec_block_sum(rn, &sh);
+                    xn = spec_block_sum(xn, &sh);
+                    // (the plane comes from the SQUARED shifted matrix: with another eigenvalue very close to the pair
+                    // its residual floors near eps / gap^2; the change between launches then still decides)
+                    double res = sqrt(rn / fmax(xn, 1e-300));
+                    if (!ar.init) {
+                        const double dr = th_re - ritz[2 * kMaxP + wv], di = th_im - ritz[3 * kMaxP + wv];
+                        res = fmin(res, sqrt(dr * dr + di * di) / fmax(sqrt(th_re * th_re + th_im * th_im), 1e-300));
+                    }
+                    worst = fmax(worst, res);
+                    continue;
+                }
                 const double dr = th_re - ritz[2 * kMaxP + wv], di = th_im - ritz[3 * kMaxP + wv];
                 const double mag = sqrt(th_re * th_re + th_im * th_im);
                 const double ch = ar.init ? 1.0 : sqrt(dr * dr + di * di) / fmax(mag, 1e-300);   // no history yet

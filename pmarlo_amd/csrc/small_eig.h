@@ -408,8 +408,11 @@ SE_HD inline void eigenvector(const double* h, int n, int ld, double theta, doub
 // three steps of inverse iteration; the back substitution is column oriented (each y_i is broadcast and
 // removed from the rows above), so sums are taken in a different order than in the scalar routine (last
 // digits may differ).  work: n*n + 2n doubles.  All lanes call it with the same arguments.
+// theta_im != 0: a vector u of the REAL invariant plane of the complex pair theta +- i theta_im, as the null vector of
+// (H - theta)^2 + theta_im^2 = H^2 - 2 theta H + |.|^2 (real arithmetic throughout); the partner is
+// v = (theta u - H u) / theta_im, so that H (u + i v) = (theta + i theta_im)(u + i v).
 __device__ inline void eigenvector_wave(const double* h, int n, int ld, double theta, volatile double* y,
-                                        volatile double* work) {
+                                        volatile double* work, double theta_im = 0.0) {
 #define SE_SYNC() __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier()
     const int lane = threadIdx.x & 63;
     volatile double* m = work;            // n x n
@@ -418,8 +421,15 @@ __device__ inline void eigenvector_wave(const double* h, int n, int ld, double t
     double scale = 0.0;
     for (int e = lane; e < n * n; e += 64) {
         const int i = e / n, j = e - i * n;
-        const double v = h[i * ld + j];
-        m[e] = v - (i == j ? theta : 0.0);
+        double v = h[i * ld + j];
+        if (theta_im != 0.0) {
+            double q = 0.0;
+            for (int k = 0; k < n; ++k) q = fma(h[i * ld + k], h[k * ld + j], q);
+            v = q - 2.0 * theta * v + (i == j ? theta * theta + theta_im * theta_im : 0.0);
+            m[e] = v;
+        } else {
+            m[e] = v - (i == j ? theta : 0.0);
+        }
         scale = fmax(scale, fabs(v));
     }
     for (int off = 32; off > 0; off >>= 1) scale = fmax(scale, __shfl_xor(scale, off, 64));
