@@ -435,11 +435,17 @@ msm_status launch_counts(msm_ctx* ctx, const int32_t* d_labels, const double* d_
                 unsigned int* offs = (unsigned int*)((char*)ctx->aux + elem_bytes);
                 unsigned int* valid = offs + (size_t)(buckets + 1) * chunks;
                 const size_t lds1 = (size_t)slots * 8 + (size_t)(2 * kBucketsMax + 2) * sizeof(unsigned int) + (size_t)chunk * 2;
+                if (lds1 > 48 * 1024)
+                    MSM_HIP(ctx, hipFuncSetAttribute((const void*)count_bucket_scatter_kernel,
+                                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1));
                 hipLaunchKernelGGL(count_bucket_scatter_kernel, dim3(chunks), dim3(kThreads), lds1, ctx->stream, d_labels, st,
                                    k, R, buckets, chunk, slots, elems, offs, valid);
                 int copies = 1;
                 while (copies < kThreads / 64 && (size_t)2 * copies * bin_bytes <= (size_t)kBinCopiesBytes) copies *= 2;
                 const size_t lds2 = (size_t)copies * bin_bytes + (size_t)(2 * kThreads + 1) * sizeof(unsigned int);
+                if (lds2 > 48 * 1024)
+                    MSM_HIP(ctx, hipFuncSetAttribute((const void*)count_bucket_bin_kernel,
+                                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
                 hipLaunchKernelGGL(count_bucket_bin_kernel, dim3(8 * ((buckets + 7) / 8)), dim3(kThreads), lds2, ctx->stream,
                                    (const unsigned short*)elems, (const unsigned int*)offs, chunks, chunk, k, R, buckets, copies,
                                    (unsigned long long*)d_counts, (const unsigned int*)valid, (unsigned long long*)d_pairs);
