@@ -1020,12 +1020,20 @@ class Engine:
         # to the caller and therefore always fresh
         cache = getattr(self, "_spec_cache", None)
         key = (k, B, max(n_its, 1))
+        m_its = max(n_its, 1)
         if cache is None or cache[0] != key or cache[1].size < ws_bytes:
-            cache = (key, self.empty((ws_bytes,), np.uint8), self.empty((B, 128), np.float64),
-                     self.empty((B,), np.float64), self.empty((B,), np.int32),
-                     self.empty((B, max(n_its, 1)), np.float64), self.empty((B, max(n_its, 1)), np.float64))
+            # the small outputs share ONE allocation [ritz B x 128 | change B | its_eig B x m | its_ts B x m | status B i32]:
+            # one copy to the host at the end instead of five
+            outs = self.empty((B * (129 + 2 * m_its) + (B + 1) // 2,), np.float64)
+            cache = (key, self.empty((ws_bytes,), np.uint8), outs)
             self._spec_cache = cache
-        _, ws, ritz, change, status, its_eig, its_ts = cache
+        _, ws, outs = cache
+        o_change, o_eig, o_ts, o_status = B * 128, B * 129, B * (129 + m_its), B * (129 + 2 * m_its)
+        ritz = self.wrap(outs.ptr, (B, 128), np.float64)
+        change = self.wrap(outs.ptr + 8 * o_change, (B,), np.float64)
+        its_eig = self.wrap(outs.ptr + 8 * o_eig, (B, m_its), np.float64)
+        its_ts = self.wrap(outs.ptr + 8 * o_ts, (B, m_its), np.float64)
+        status = self.wrap(outs.ptr + 8 * o_status, (B,), np.int32)
         pi = self.empty((B, k), np.float64) if want_pi else None
         vecs = self.empty((B, n_vecs, k), np.float64) if n_vecs else None
         lag_d = self.to_device(np.asarray(lags if lags is not None else np.ones(B), np.float64).reshape(B))
@@ -1064,26 +1072,26 @@ class Engine:
                 if remaining > 6:
                     p = int(min(32, k))
                     ws = self.empty((int(lib.msm_spectrum_workspace_bytes(k, p, B)),), np.uint8)
-                    self._spec_cache = (key, ws, ritz, change, status, its_eig, its_ts)
+                    self._spec_cache = (key, ws, outs)
                     restart, since_restart, worst = True, 0, float("inf")
         else:
             if not allow_unconverged:
                 raise _lib.MsmError(
                     f"msm_spectrum: residual {worst:.3e} > {tol:.1e} after {launches} launches "
                     "(leading eigenvalues too clustered for subspace iteration)")
+        host = outs.to_host()
+        ch = host[o_change:o_change + B].copy()
         if os.environ.get("MSM_SPEC_TRACE"):
-            ch = change.to_host()
             print(f"msm_spectrum: B={B} k={k} p={p} powered={Tpow is not None} n_iter={n_iter} launches={launches} "
                   f"worst={worst:.2e} unconverged={int(np.sum(ch > tol))}", file=sys.stderr)
-        st = status.to_host()
+        st = host[o_status:].view(np.int32)[:B]
         if np.any(st != 0):
             raise _lib.MsmError(f"msm_spectrum: hqr did not converge (status {st.tolist()})")
-        r = ritz.to_host()
-        out = {"ritz": r[:, :32] + 1j * r[:, 32:64], "p": p, "launches": launches,
-               "residual": change.to_host(), "pi": pi, "vecs": vecs}
+        r = host[:B * 128].reshape(B, 128)
+        out = {"ritz": r[:, :32] + 1j * r[:, 32:64], "p": p, "launches": launches, "residual": ch, "pi": pi, "vecs": vecs}
         if n_its:
-            out["its_eig"] = its_eig.to_host()
-            out["its_ts"] = its_ts.to_host()
+            out["its_eig"] = host[o_eig:o_eig + B * m_its].reshape(B, m_its).copy()
+            out["its_ts"] = host[o_ts:o_ts + B * m_its].reshape(B, m_its).copy()
         return out
 
 
