@@ -203,3 +203,30 @@ def test_spectrum_of_low_rank_chains_with_and_without_powering(engine, k, rank):
     for sq in (0, 2):
         out = engine.spectrum(engine.to_device(P), n_its=n_its, lags=[1.0], squarings=sq)
         np.testing.assert_allclose(np.sort(out["its_eig"][0])[::-1], ev, rtol=1e-7)
+
+
+def test_complex_ritz_pairs_get_a_true_residual(engine):
+    """A three-block chain with a cyclic drift between the blocks: the slowest processes are a COMPLEX pair.  Its
+    convergence is judged by the residual of the real invariant plane (not by the change between two launches), so
+    the solve may finish in its first launch, and the reported residual must be honest: the Ritz values agree with
+    numpy to the tolerance the residual promises."""
+    rng = np.random.default_rng(5)
+    k, w = 96, 32
+    P = np.zeros((k, k))
+    for b in range(3):
+        blk = rng.random((w, w)) + 0.2
+        P[w * b:w * b + w, w * b:w * b + w] = blk / blk.sum(1, keepdims=True)
+    eps = 0.02
+    shift = np.roll(np.eye(k), w, axis=1)                      # state i of block b -> state i of block b + 1
+    T = (1.0 - eps) * P + eps * shift
+    ev = np.linalg.eigvals(T)
+    ev = ev[np.argsort(-np.abs(ev))]
+    assert abs(ev[1].imag) > 1e-3 and abs(ev[1] - np.conj(ev[2])) < 1e-12        # the pair the test is about
+    for sq in (0, 2):
+        out = engine.spectrum(engine.to_device(T), n_its=2, lags=[1.0], squarings=sq, tol=1e-10)
+        got = out["ritz"][0][:3]
+        assert abs(got[0] - 1.0) < 1e-9
+        assert min(abs(got[1] - ev[1]), abs(got[1] - ev[2])) < 1e-8
+        assert abs(got[1] - np.conj(got[2])) < 1e-12
+        assert float(out["residual"][0]) <= 1e-10
+        assert out["launches"] <= 3
