@@ -628,6 +628,7 @@ __global__ __launch_bounds__(kSolveThreads) void spec_persist_kernel(SpecArgs ar
         const int n = ar.n_ptr ? ar.n_ptr[b] : ar.n_fixed;
         if (n <= 0 || spec_frozen(ar, b)) continue;      // the same decision on every member
         const int p = min(ar.p, n);
+        if (p == n) continue;       // the basis spans the whole space: nothing to iterate (see spec_step_kernel)
         const double* T = ar.T + (size_t)b * ar.t_stride;
         const int j0 = r * pa.cols, nj = max(0, min(n, j0 + pa.cols) - j0);
         // this member's columns of T
@@ -792,6 +793,10 @@ __global__ __launch_bounds__(kSolveThreads) void spec_step_kernel(SpecArgs ar, i
         return;
     }
     const int p = min(ar.p, n);
+    // A basis of the WHOLE space (p = n: small matrices) needs no iterations -- the Rayleigh-Ritz step on any orthonormal
+    // basis of it returns the eigenvalues of T -- and must not get them: T'Z of a singular T is rank-deficient and its
+    // Cholesky-QR breaks down (NaN Ritz values, "hqr did not converge").  The seeded basis stays as it is until the finish.
+    if (p == n && !(mode & (kStepInit | kStepFinish))) return;
     if (mode & kStepInit) {
         for (int e = tid; e < n * p; e += blockDim.x) {
             const int c = e % p;

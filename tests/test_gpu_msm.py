@@ -230,3 +230,23 @@ def test_complex_ritz_pairs_get_a_true_residual(engine):
         assert abs(got[1] - np.conj(got[2])) < 1e-12
         assert float(out["residual"][0]) <= 1e-10
         assert out["launches"] <= 3
+
+
+@pytest.mark.parametrize("k", [4, 7, 12])
+def test_small_singular_matrices_need_no_iterations(engine, k):
+    """k below the subspace size: the basis spans the whole space, the Rayleigh-Ritz step alone gives the spectrum, and a
+    singular T (two states with identical rows) must not meet the Cholesky-QR of T'Z, whose Gram matrix it makes singular."""
+    rng = np.random.default_rng(k)
+    P = rng.random((k, k)) + 0.05
+    P[1] = P[0]                                   # rank k - 1: an exact zero eigenvalue
+    P /= P.sum(1, keepdims=True)
+    n_its = k - 1
+    out = engine.spectrum(engine.to_device(P), n_its=n_its, lags=[1.0])
+    assert out["launches"] == 1
+    ev = np.linalg.eigvals(P)
+    want = np.sort(np.abs(np.sort(ev.real)[::-1][1:1 + n_its]))[::-1]
+    got = np.sort(np.nan_to_num(out["its_eig"][0], nan=0.0))[::-1]
+    real = np.abs(ev.imag) < 1e-12
+    if real.all():
+        np.testing.assert_allclose(got, np.clip(want, 1e-12, None), atol=1e-9)
+    np.testing.assert_allclose(out["pi"].to_host()[0] @ P, out["pi"].to_host()[0], atol=1e-12)
