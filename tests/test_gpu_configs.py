@@ -140,3 +140,30 @@ def test_c5_wide_features_k2000(engine):
     assert int(pairs.to_host()[0]) == p
     T = engine.transition_matrix(counts, mode=0)["T"].to_host()
     np.testing.assert_array_equal(T, npport.normalise_counts(C.astype(float)))
+
+
+def test_c5_shape_at_size_labels_on_a_sample(engine):
+    """C5 near its per-GPU size (300 K x 256, k = 2000; the full 1.25 M differs only in the number of frame groups a
+    workgroup walks): every label of 4000 sampled frames against the pinned fp64 arg-min of the C oracle, the rest through a
+    size-independent property -- the distance the device reports for a frame is the distance to the centre it names,
+    and no centre of a sampled subset is nearer."""
+    n, F, k = 300_000, 256, 2000
+    rng = np.random.default_rng(9)
+    X = _gen.correlated_series(n, F, seed=99)
+    centers_h = X[np.sort(rng.choice(n, k, replace=False))].astype(np.float64) + 1e-3 * rng.normal(size=(k, F))
+    xd, cd = engine.to_device(X), engine.to_device(centers_h)
+    md = engine.empty((n,), np.float64)
+    lab = engine.kmeans_assign(xd, cd, mindist=md).to_host()
+    dist = md.to_host()
+    idx = np.sort(rng.choice(n, 4000, replace=False))
+    np.testing.assert_array_equal(lab[idx], cport.kmeans_assign(X[idx].astype(np.float64), centers_h))
+    assert lab.min() >= 0 and lab.max() < k
+    # reported distance = squared distance to the named centre (1e-9 relative), on another 20000 frames
+    jdx = np.sort(rng.choice(n, 20_000, replace=False))
+    d_named = ((X[jdx].astype(np.float64) - centers_h[lab[jdx]]) ** 2).sum(1)
+    np.testing.assert_allclose(dist[jdx], d_named, rtol=1e-9, atol=1e-9)
+    # and a random subset of 64 centres holds none that is nearer
+    sub = rng.choice(k, 64, replace=False)
+    Xj = X[jdx].astype(np.float64)
+    d_sub = ((Xj * Xj).sum(1)[:, None] + (centers_h[sub] ** 2).sum(1)[None, :] - 2.0 * Xj @ centers_h[sub].T).min(1)
+    assert np.all(d_sub >= d_named * (1 - 1e-9) - 1e-9)
