@@ -32,7 +32,7 @@ def main():
     emit("prof_spec", "r03_its_spectrum_kernel_stats", "Round 3: one implied-timescale solve, k = 500 microstates, 5 timescales",
          "rocprofv3 --kernel-trace --stats --output-format csv -- python3 tools/time_spectrum.py 500 (tools/run/prof_spec.sh)",
          "Three solves (the script repeats the call) of a metastable 6-block chain; each solve = 2 squarings (T^4), the seeding "
-         "step, ONE launch of the persistent subspace iteration on T^4 (4 iterations) and one finishing launch "
+         "step, ONE launch of the persistent subspace iteration on T^4 (6 iterations) and one finishing launch "
          "(product with T + Rayleigh-Ritz, residuals of real and complex pairs).  " + " ".join(spec))
     its = result_lines(ROOT / "gpurun_out/prof_its.log", r"k=200 L=50|numpy eigvals")
     emit("prof_its", "r03_its_scan_kernel_stats", "Round 3: Bayesian ITS scan (k = 200, 50 lags x 100 posterior samples = 5000 matrices)",
